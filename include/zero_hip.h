@@ -1,0 +1,173 @@
+/* zero_hip.h — C ABI of libzero_hip.so (gfx950 / MI355X).
+ *
+ * The reference (facebookresearch/zero) has no FFI of its own for this path: every
+ * kernel on its hot path is dispatched by PyTorch/ATen from inside the transformers
+ * model classes.  The entry points below are therefore the ATen
+ * operator calls those classes make, one `extern "C"` function per kernel family; each
+ * comment names the reference/transformers call site it replaces ("tf:" = the
+ * transformers package the reference imports, "ref:" = /root/reference/src).
+ *
+ * Conventions (SURVEY.md §8b "Lower"):
+ *   - plain device pointers + int64 sizes, no torch types;
+ *   - bf16 tensors are raw uint16 bits, row-major, leading dimensions in ELEMENTS;
+ *   - every call is asynchronous on `stream`, allocates nothing, never synchronises,
+ *     never changes the current device; the caller owns every buffer;
+ *   - returns 0 on success, a negative errno-style code otherwise
+ *     (-22 invalid argument / unsupported shape, -5 launch failure);
+ *   - 16-byte aligned base pointers; feature dimensions are multiples of 8.
+ */
+#ifndef ZERO_HIP_H_
+#define ZERO_HIP_H_
+
+#include <stdint.h>
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZK_ABI_VERSION 1
+int zk_abi_version(void);
+
+/* ---- GEMM -------------------------------------------------------------------------
+ * C[m][n] = epi( alpha * sum_k A(m,k) B(n,k) ), fp32 accumulate on MFMA, bf16 in/out.
+ *   transA=0: A [M][lda] (k contiguous)   transA=1: A [K][lda] (m contiguous)
+ *   transB=0: B [N][ldb] (k contiguous)   transB=1: B [K][ldb] (n contiguous)
+ * Replaces F.linear in tf:models/clip/modeling_clip.py:309-311,333,347-349 (q/k/v/out,
+ * fc1/fc2, biased), the patch conv tf:clip:209 (as im2col GEMM), ref:models/adapter.py:95
+ * (adapter Linear->GELU->Linear), tf:models/llama/modeling_llama.py:175 (gate/up/down),
+ * :254-256,280 (q/k/v/o), :480 (lm_head), and their autograd dgrad (transB=1) / wgrad
+ * (transA=1, transB=1) products triggered by ref:train.py:567.
+ * Epilogues: bias add; QUICK_GELU (tf:activations.py:117-123) / GELU_ERF (nn.GELU,
+ * ref:adapter.py:36) with optional copy of the bf16 pre-activation to aux_out;
+ * residual add (tf:clip:376,381; tf:llama:306,321); MUL_D*: multiply by the activation
+ * derivative at aux_in (backward of the fused activation); accumulate: C += result.
+ */
+enum {
+  ZK_EPI_NONE = 0,
+  ZK_EPI_QUICK_GELU = 1,
+  ZK_EPI_GELU_ERF = 2,
+  ZK_EPI_MUL_DQUICK_GELU = 3,
+  ZK_EPI_MUL_DGELU_ERF = 4
+};
+int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K,
+                 int64_t lda, int64_t ldb, int64_t ldc, int transA, int transB, int epilogue,
+                 const void* bias, const void* residual, int64_t ldr, void* aux_out,
+                 const void* aux_in, int64_t ldaux, float alpha, const float* alpha_dev,
+                 int accumulate, hipStream_t stream);
+
+/* ---- fused attention ----------------------------------------------------------------
+ * softmax(Q K^T * scale [+ causal mask]) V, flash-style (no S x S matrix in HBM).
+ * Replaces F.scaled_dot_product_attention as called by
+ * tf:integrations/sdpa_attention.py:154-163 from tf:clip:317-330 (bidirectional, 16
+ * heads, head_dim 64) and tf:llama:264-277 (is_causal, enable_gqa, head_dim 128), and its
+ * backward.  q/k/v/o are [B][S][heads][head_dim] views with a row (token) stride in
+ * elements, so they may alias column slices of one packed qkv buffer.  lse is
+ * [B][Hq][S] fp32 (natural-log-sum-exp of the scaled scores), written by fwd, read by bwd.
+ * delta is a [B][Hq][S] fp32 scratch written by bwd.  head_dim in {64, 128}.
+ */
+int zk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B,
+                int64_t S, int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk,
+                int64_t ldv, int64_t ldo, float scale, int causal, hipStream_t stream);
+int zk_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                const float* lse, float* delta, void* dq, void* dk, void* dv, int64_t B,
+                int64_t S, int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk,
+                int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale,
+                int causal, hipStream_t stream);
+
+/* ---- LayerNorm (tf:clip:358-360,370,379,605,642; ref:adapter.py:94) ------------------
+ * y = (x - mean) * rstd * gamma + beta over the last dim D (<= 8192, multiple of 8),
+ * fp32 statistics.  mean/rstd [rows] fp32 are optional outputs of fwd (needed by bwd).
+ * bwd: dx = dres + LN'(dy); dgamma/dbeta are ACCUMULATED into fp32 [D] buffers (may be
+ * null when the affine parameters are frozen).
+ */
+int zk_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean,
+                     float* rstd, int64_t rows, int64_t D, float eps, hipStream_t stream);
+int zk_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean,
+                     const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                     int64_t rows, int64_t D, hipStream_t stream);
+
+/* ---- RMSNorm (tf:llama:62-67) ----------------------------------------------------------
+ * y = w * bf16(x * rsqrt(mean(x^2) + eps)); bwd gives dx = dres + RMS'(dy) (w frozen).
+ */
+int zk_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t D,
+                   float eps, hipStream_t stream);
+int zk_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd,
+                   const void* dres, void* dx, int64_t rows, int64_t D, hipStream_t stream);
+
+/* ---- RoPE (tf:llama:130-160; cos/sin table tf:llama:113-127) ---------------------------
+ * In place on `heads` consecutive heads of width head_dim inside rows of stride ld:
+ * x' = x*cos + rotate_half(x)*sin, half-split layout.  cos/sin are [S][head_dim/2] fp32
+ * holding the bf16-rounded table values; row r of x is position r % S.  inverse != 0
+ * applies the transposed rotation (backward).
+ */
+int zk_rope(void* x, const float* cos_t, const float* sin_t, int64_t rows, int64_t S,
+            int64_t heads, int64_t head_dim, int64_t ld, int inverse, hipStream_t stream);
+
+/* ---- SwiGLU (tf:llama:175) --------------------------------------------------------------
+ * gu is [rows][2F] = [gate | up]; h = silu(gate) * up.  bwd writes d_gu [rows][2F].
+ */
+int zk_swiglu_fwd(const void* gu, void* h, int64_t rows, int64_t F, hipStream_t stream);
+int zk_swiglu_bwd(const void* dh, const void* gu, void* dgu, int64_t rows, int64_t F,
+                  hipStream_t stream);
+
+/* ---- column sum: bias gradients (autograd of the biased Linears) -----------------------
+ * out[n] += sum_m dy[m][n], fp32 accumulation buffer.
+ */
+int zk_colsum(const void* dy, float* out, int64_t rows, int64_t N, int64_t ld,
+              hipStream_t stream);
+
+/* ---- activation backward (autograd of tf:activations.py:117-123 / nn.GELU) -------------
+ * dx = dy * act'(pre), kind = ZK_EPI_QUICK_GELU | ZK_EPI_GELU_ERF; in place allowed.
+ */
+int zk_act_bwd(const void* dy, const void* pre, void* dx, int64_t n, int kind,
+               hipStream_t stream);
+
+/* ---- patch embedding front end (tf:clip:202-218) -----------------------------------------
+ * im2col: pixels [B][3][H][W] bf16 -> cols [B*G*G][Kpad] (k = c*P*P + i*P + j, zero padded).
+ * embed_finish: out[b][0] = cls + pos[0]; out[b][1+p] = bf16(patch[b*G*G+p]) + pos[1+p].
+ */
+int zk_patch_im2col(const void* pixels, void* cols, int64_t B, int64_t H, int64_t W, int64_t P,
+                    int64_t Kpad, hipStream_t stream);
+int zk_embed_finish(const void* patch, const void* cls, const void* pos, void* out, int64_t B,
+                    int64_t T, int64_t D, hipStream_t stream);
+
+/* ---- row gather / splice (ref:methods/engine_ar_instruction_llama.py:186-236) -----------
+ * dst[r] = src_table_k[idx] by a per-row source code:  code >= 0 : table0[code]
+ * (token embedding, wte); code == -1 : zeros (right padding); code <= -2 : table1[-2-code]
+ * (row of the image-embedding block).  Rows are D bf16.  gather_rows_add: dst[r] += ...
+ * is used for the backward scatter through the inverse map.
+ */
+int zk_gather_rows(const void* table0, const void* table1, const int32_t* codes, void* dst,
+                   int64_t rows, int64_t D, int accumulate, hipStream_t stream);
+
+/* ---- cross entropy on bf16 logits (ref:engine:280-305) -----------------------------------
+ * For each row: fp32 log-softmax over V, loss = -logp[target] unless target == -100.
+ * Adds the row losses into loss_sum[0] (fp32) and the number of non-ignored rows into
+ * loss_sum[1]; when dlogits != null writes (softmax - onehot) (0 for ignored rows) as bf16
+ * (may alias logits).
+ */
+int zk_cross_entropy(const void* logits, const int32_t* targets, float* loss_sum, void* dlogits,
+                     int64_t rows, int64_t V, int64_t ld, hipStream_t stream);
+
+/* ---- optimizer tail (ref:train.py:570-580: clip_grad_norm_ + AdamW.step) -----------------
+ * sumsq: out[0] += sum(g^2) over a flat bf16 buffer.  adamw_step: flat bf16 params/grads,
+ * fp32 moments; the clip coefficient min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) is
+ * computed on the device from sumsq (max_norm <= 0: no clipping); grad_scale multiplies
+ * every gradient first (1/world_size for the DDP average).
+ */
+int zk_sumsq(const void* g, float* out, int64_t n, float scale, hipStream_t stream);
+int zk_adamw_step(void* p, const void* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, float max_norm,
+                  const float* sumsq, float grad_scale, hipStream_t stream);
+
+/* ---- fp32 -> bf16 finalize for accumulated parameter gradients ---------------------------
+ * dst = bf16(src * scale) or dst = bf16(float(dst) + src * scale) when accumulate.
+ */
+int zk_f32_to_bf16(const float* src, void* dst, int64_t n, float scale, int accumulate,
+                   hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZERO_HIP_H_ */

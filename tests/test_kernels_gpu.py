@@ -1,0 +1,357 @@
+"""Per-kernel parity: each C-ABI entry point against a plain PyTorch fp32 reference of the
+same op, on the same bf16-rounded inputs.  Tolerances are stated per test: outputs are
+bf16 (eps = 2^-8 = 3.9e-3), accumulation is fp32."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from zero_amd import ops
+
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a = a.float(); b = b.float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(DEV)
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (577 * 3, 1024, 640), (130, 72, 40), (64, 3072, 1024)])
+def test_gemm_nt(M, N, K):
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    c = ops.gemm(a, b)
+    ref = a.float() @ b.float().t()
+    assert relerr(c, ref) < 6e-3
+
+
+def test_gemm_layout_exact_integers():
+    # A = identity-like probe with an ASYMMETRIC B catches any row/col swap or k permutation
+    M = N = K = 128
+    a = torch.eye(M, K, device=DEV).to(torch.bfloat16)
+    b = (torch.arange(N * K, device=DEV).reshape(N, K) % 251 - 125).to(torch.bfloat16)
+    c = ops.gemm(a, b)
+    assert torch.equal(c.float(), b.float().t())
+    a2 = (torch.arange(M * K, device=DEV).reshape(M, K) % 13 - 6).to(torch.bfloat16)
+    b2 = (torch.arange(N * K, device=DEV).reshape(N, K) % 7 - 3).to(torch.bfloat16)
+    ref = a2.float() @ b2.float().t()
+    got = ops.gemm(a2, b2).float()
+    assert torch.equal(got, ref.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 264, 136), (1154, 1024, 4096)])
+def test_gemm_transb_dgrad(M, N, K):
+    # dx[M,N] = dy[M,K] @ W[K,N]  (W stored [out=K, in=N]: n contiguous)
+    dy, w = rnd(M, K, seed=3), rnd(K, N, seed=4)
+    c = ops.gemm(dy, w, trans_b=True)
+    assert relerr(c, dy.float() @ w.float()) < 6e-3
+
+
+@pytest.mark.parametrize("T,No,Ki", [(128, 128, 128), (577 * 2, 264, 136), (1000, 1024, 1024)])
+def test_gemm_wgrad(T, No, Ki):
+    # dW[No,Ki] = dY[T,No]^T @ X[T,Ki]
+    dy, x = rnd(T, No, seed=5), rnd(T, Ki, seed=6)
+    c = ops.gemm(dy, x, trans_a=True, trans_b=True)
+    assert relerr(c, dy.float().t() @ x.float()) < 6e-3
+    c2 = ops.gemm(dy, x, trans_a=True, trans_b=True, out=c.clone(), accumulate=True)
+    assert relerr(c2, 2 * (dy.float().t() @ x.float())) < 1e-2
+
+
+def test_gemm_transa_only():
+    a, b = rnd(200, 136, seed=7), rnd(72, 200, seed=8)   # A stored [K=200][M=136], B [N=72][K=200]
+    c = ops.gemm(a, b, trans_a=True)
+    assert relerr(c, a.float().t() @ b.float().t()) < 6e-3
+
+
+def test_gemm_strided_views():
+    buf = rnd(300, 512, seed=9)
+    a = buf[:, 128:384]                       # [300,256] view, lda 512
+    w = rnd(264, 256, seed=10)
+    outbuf = torch.zeros(300, 1024, dtype=torch.bfloat16, device=DEV)
+    out = outbuf[:, 512:776]
+    ops.gemm(a, w, out=out)
+    assert relerr(out, a.float() @ w.float().t()) < 6e-3
+    assert outbuf[:, :512].abs().max() == 0 and outbuf[:, 776:].abs().max() == 0
+
+
+def test_gemm_epilogues():
+    M, N, K = 300, 264, 136
+    a, w, bias, res = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=0.1), rnd(N, seed=13), rnd(M, N, seed=14)
+    pre = a.float() @ w.float().t() + bias.float()
+    assert relerr(ops.gemm(a, w, bias=bias), pre) < 6e-3
+    pre_b = pre.to(torch.bfloat16).float()
+    aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    got = ops.gemm(a, w, bias=bias, epilogue=ops.EPI_QUICK_GELU, aux_out=aux)
+    assert relerr(aux, pre) < 6e-3
+    assert relerr(got, pre_b * torch.sigmoid(1.702 * pre_b)) < 8e-3
+    got = ops.gemm(a, w, bias=bias, epilogue=ops.EPI_GELU_ERF)
+    assert relerr(got, F.gelu(pre_b)) < 8e-3
+    got = ops.gemm(a, w, bias=bias, residual=res)
+    assert relerr(got, pre_b + res.float()) < 6e-3
+    alpha_dev = torch.tensor([0.25], device=DEV)
+    got = ops.gemm(a, w, alpha=2.0, alpha_dev=alpha_dev)
+    assert relerr(got, 0.5 * (a.float() @ w.float().t())) < 6e-3
+    # backward-fused epilogues: dy W  *  act'(pre)
+    h = rnd(M, N, seed=15)
+    dyy, w2 = rnd(M, K, seed=16), rnd(K, N, seed=17, scale=0.1)
+    base = dyy.float() @ w2.float()
+    hf = h.float().requires_grad_(True)
+    (hf * torch.sigmoid(1.702 * hf)).sum().backward()
+    got = ops.gemm(dyy, w2, trans_b=True, epilogue=ops.EPI_MUL_DQUICK_GELU, aux_in=h)
+    assert relerr(got, base * hf.grad) < 8e-3
+    hf = h.float().requires_grad_(True)
+    F.gelu(hf).sum().backward()
+    got = ops.gemm(dyy, w2, trans_b=True, epilogue=ops.EPI_MUL_DGELU_ERF, aux_in=h)
+    assert relerr(got, base * hf.grad) < 8e-3
+
+
+def test_gemm_rejects_bad_shapes():
+    a, b = rnd(16, 20, seed=1), rnd(16, 20, seed=2)   # K = 20 is not a multiple of 8
+    with pytest.raises(RuntimeError):
+        ops.gemm(a, b)
+    with pytest.raises(ValueError):
+        ops.gemm(a.cpu(), b.cpu())
+
+
+# ------------------------------------------------------------------ attention
+def ref_attention(q, k, v, causal, scale):
+    # q [B,Hq,S,hd] fp32 (requires_grad), k/v [B,Hkv,S,hd]
+    B, Hq, S, hd = q.shape
+    rep = Hq // k.shape[1]
+    kk = k.repeat_interleave(rep, dim=1)
+    vv = v.repeat_interleave(rep, dim=1)
+    s = (q @ kk.transpose(-1, -2)) * scale
+    if causal:
+        mask = torch.ones(S, S, dtype=torch.bool, device=q.device).tril()
+        s = s.masked_fill(~mask, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return p @ vv, torch.logsumexp(s, dim=-1)
+
+
+@pytest.mark.parametrize("B,S,Hq,Hkv,hd,causal", [
+    (2, 577, 16, 16, 64, False),      # CLIP-L/14-336 geometry
+    (1, 64, 2, 2, 64, False),
+    (2, 200, 6, 2, 128, True),        # ragged S, GQA rep 3
+    (1, 768, 24, 8, 128, True),       # Llama-3.2-3B geometry at S = 768
+    (1, 130, 4, 1, 128, False),
+    (1, 100, 2, 2, 64, True),
+])
+def test_attention_fwd_bwd(B, S, Hq, Hkv, hd, causal):
+    W = (Hq + 2 * Hkv) * hd
+    qkv = rnd(B * S, W, seed=21)
+    q2, k2, v2 = qkv[:, :Hq * hd], qkv[:, Hq * hd:(Hq + Hkv) * hd], qkv[:, (Hq + Hkv) * hd:]
+    scale = hd ** -0.5
+    o, lse = ops.attn_fwd(q2, k2, v2, B, S, Hq, Hkv, hd, scale, causal)
+    qf = q2.float().reshape(B, S, Hq, hd).transpose(1, 2).detach().requires_grad_(True)
+    kf = k2.float().reshape(B, S, Hkv, hd).transpose(1, 2).detach().requires_grad_(True)
+    vf = v2.float().reshape(B, S, Hkv, hd).transpose(1, 2).detach().requires_grad_(True)
+    ro, rlse = ref_attention(qf, kf, vf, causal, scale)
+    ro2 = ro.transpose(1, 2).reshape(B * S, Hq * hd)
+    assert relerr(o, ro2) < 8e-3, "o"
+    assert (lse - rlse).abs().max().item() < 2e-3, "lse"
+    d_o = rnd(B * S, Hq * hd, seed=22)
+    ro2.backward(d_o.float())
+    dqkv = torch.full((B * S, W), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dq, dk, dv = dqkv[:, :Hq * hd], dqkv[:, Hq * hd:(Hq + Hkv) * hd], dqkv[:, (Hq + Hkv) * hd:]
+    ops.attn_bwd(q2, k2, v2, o, d_o, lse, dq, dk, dv, B, S, Hq, Hkv, hd, scale, causal)
+    assert relerr(dq, qf.grad.transpose(1, 2).reshape(B * S, -1)) < 1.5e-2, "dq"
+    assert relerr(dk, kf.grad.transpose(1, 2).reshape(B * S, -1)) < 1.5e-2, "dk"
+    assert relerr(dv, vf.grad.transpose(1, 2).reshape(B * S, -1)) < 1.5e-2, "dv"
+
+
+def test_attention_online_softmax_rescale_branch():
+    # a spike late in the key sequence forces the running max to jump at a later tile
+    B, S, H, hd = 1, 256, 1, 64
+    q = rnd(S, hd, seed=31); k = rnd(S, hd, seed=32); v = rnd(S, hd, seed=33)
+    k[200] = (q[5].float() * 4).to(torch.bfloat16)
+    o, lse = ops.attn_fwd(q, k, v, B, S, H, H, hd, hd ** -0.5, False)
+    ro, rlse = ref_attention(q.float()[None, None], k.float()[None, None], v.float()[None, None], False, hd ** -0.5)
+    assert relerr(o, ro[0, 0]) < 8e-3
+    assert (lse[0, 0] - rlse[0, 0]).abs().max().item() < 5e-3
+
+
+# ------------------------------------------------------------------ norms
+@pytest.mark.parametrize("rows,D", [(577 * 2, 1024), (37, 256), (100, 3072), (8, 4096), (5, 8192)])
+def test_layernorm_fwd(rows, D):
+    x, g, b = rnd(rows, D, seed=41, scale=2.0), rnd(D, seed=42), rnd(D, seed=43)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-5)
+    ref = F.layer_norm(x.float(), (D,), g.float(), b.float(), 1e-5)
+    assert relerr(y, ref) < 6e-3
+    assert relerr(mean, x.float().mean(-1)) < 1e-4 or (mean - x.float().mean(-1)).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("rows,D", [(577 * 2, 1024), (37, 256), (50, 3072)])
+def test_layernorm_bwd(rows, D):
+    x, g, b = rnd(rows, D, seed=44, scale=2.0), rnd(D, seed=45), rnd(D, seed=46)
+    dy, dres = rnd(rows, D, seed=47), rnd(rows, D, seed=48)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-5)
+    dgamma = torch.zeros(D, device=DEV); dbeta = torch.zeros(D, device=DEV)
+    dx = ops.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, dgamma=dgamma, dbeta=dbeta)
+    xf = x.float().requires_grad_(True); gf = g.float().requires_grad_(True); bf = b.float().requires_grad_(True)
+    F.layer_norm(xf, (D,), gf, bf, 1e-5).backward(dy.float())
+    assert relerr(dx, xf.grad + dres.float()) < 8e-3
+    assert relerr(dgamma, gf.grad) < 1e-3
+    assert relerr(dbeta, bf.grad) < 1e-3
+    dx2 = ops.layernorm_bwd(dy, x, g, mean, rstd)
+    assert relerr(dx2, xf.grad) < 8e-3
+
+
+@pytest.mark.parametrize("rows,D", [(768 * 2, 3072), (37, 256), (9, 4096), (5, 8192)])
+def test_rmsnorm(rows, D):
+    x, w = rnd(rows, D, seed=51, scale=3.0), rnd(D, seed=52)
+    y, rstd = ops.rmsnorm_fwd(x, w, 1e-5)
+    xf = x.float().requires_grad_(True)
+    nrm = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)
+    ref = w.float() * nrm
+    assert relerr(y, ref) < 8e-3
+    # exact cast-point check (tf:llama:67): w * bf16(x * rstd)
+    exact = (w.float() * nrm.detach().to(torch.bfloat16).float()).to(torch.bfloat16)
+    assert (y.float() - exact.float()).abs().max().item() <= 2 * 2 ** -8 * exact.float().abs().max().item()
+    dy, dres = rnd(rows, D, seed=53), rnd(rows, D, seed=54)
+    ref.backward(dy.float())
+    dx = ops.rmsnorm_bwd(dy, x, w, rstd, dres=dres)
+    assert relerr(dx, xf.grad + dres.float()) < 8e-3
+
+
+# ------------------------------------------------------------------ rope / swiglu / act
+def test_rope_matches_rotate_half_and_inverts():
+    S, H, hd, Hk = 50, 3, 128, 1
+    rows = 2 * S
+    W = (H + 2 * Hk) * hd
+    qkv = rnd(rows, W, seed=61)
+    inv = 1.0 / (500000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = torch.outer(torch.arange(S).float(), inv)
+    cos_t = fr.cos().to(torch.bfloat16).float().to(DEV).contiguous()
+    sin_t = fr.sin().to(torch.bfloat16).float().to(DEV).contiguous()
+    orig = qkv.clone()
+    ops.rope_(qkv, cos_t, sin_t, S, H + Hk, hd)
+    x = orig[:, :(H + Hk) * hd].float().reshape(rows, H + Hk, hd)
+    c = torch.cat([cos_t, cos_t], -1).repeat(2, 1)[:, None, :]
+    s = torch.cat([sin_t, sin_t], -1).repeat(2, 1)[:, None, :]
+    rot = torch.cat([-x[..., hd // 2:], x[..., :hd // 2]], -1)
+    ref = (x * c + rot * s).reshape(rows, -1)
+    assert relerr(qkv[:, :(H + Hk) * hd], ref) < 6e-3
+    assert torch.equal(qkv[:, (H + Hk) * hd:], orig[:, (H + Hk) * hd:])      # v untouched
+    ops.rope_(qkv, cos_t, sin_t, S, H + Hk, hd, inverse=True)
+    # the bf16 table is not exactly orthonormal: cos^2+sin^2 = 1 +- 2^-8
+    assert relerr(qkv, orig) < 2e-2
+
+
+def test_swiglu_fwd_bwd():
+    rows, Fd = 300, 512
+    gu, dh = rnd(rows, 2 * Fd, seed=62, scale=2.0), rnd(rows, Fd, seed=63)
+    h = ops.swiglu_fwd(gu, Fd)
+    gf = gu.float().requires_grad_(True)
+    ref = F.silu(gf[:, :Fd]) * gf[:, Fd:]
+    assert relerr(h, ref) < 8e-3
+    ref.backward(dh.float())
+    dgu = ops.swiglu_bwd(dh, gu, Fd)
+    assert relerr(dgu, gf.grad) < 8e-3
+
+
+@pytest.mark.parametrize("kind", ["quick", "erf"])
+def test_act_bwd(kind):
+    pre, dy = rnd(100, 256, seed=64, scale=2.0), rnd(100, 256, seed=65)
+    pf = pre.float().requires_grad_(True)
+    (pf * torch.sigmoid(1.702 * pf) if kind == "quick" else F.gelu(pf)).backward(dy.float())
+    got = ops.act_bwd(dy, pre, ops.EPI_QUICK_GELU if kind == "quick" else ops.EPI_GELU_ERF)
+    assert relerr(got, pf.grad) < 8e-3
+
+
+def test_colsum():
+    dy = rnd(1154, 1032, seed=66)
+    out = torch.zeros(1032, device=DEV)
+    ops.colsum_(dy, out)
+    assert relerr(out, dy.float().sum(0)) < 1e-4
+    view = dy[:, 8:520]
+    out2 = torch.ones(512, device=DEV)
+    ops.colsum_(view, out2)
+    assert relerr(out2, view.float().sum(0) + 1) < 1e-4
+
+
+# ------------------------------------------------------------------ patch embedding / gather / CE / optimizer
+def test_patch_embed_front_end():
+    B, H, P, D = 3, 42, 14, 1024
+    px = rnd(B, 3, H, H, seed=71)
+    w = rnd(D, 3, P, P, seed=72, scale=0.05)
+    cls, pos = rnd(D, seed=73), rnd(10, D, seed=74)
+    Kpad = 640
+    cols = ops.patch_im2col(px, P, Kpad)
+    wp = torch.zeros(D, Kpad, dtype=torch.bfloat16, device=DEV)
+    wp[:, :588] = w.reshape(D, -1)
+    patch = ops.gemm(cols, wp)
+    out = ops.embed_finish(patch, cls, pos, B, 10, D)
+    conv = F.conv2d(px.float(), w.float(), stride=P).flatten(2).transpose(1, 2)
+    ref = torch.cat([cls.float().expand(B, 1, D), conv], 1) + pos.float()[None]
+    assert relerr(out, ref) < 8e-3
+    unf = F.unfold(px.float(), kernel_size=P, stride=P).transpose(1, 2).reshape(-1, 588)
+    assert torch.equal(cols[:, :588].float(), unf) and cols[:, 588:].abs().max() == 0
+
+
+def test_gather_rows_splice_and_accumulate():
+    D = 256
+    wte, img = rnd(50, D, seed=75), rnd(12, D, seed=76)
+    codes = torch.tensor([3, 49, -1, -2, -13, 0, -1], dtype=torch.int32, device=DEV)
+    out = ops.gather_rows(wte, img, codes, D)
+    ref = torch.stack([wte[3], wte[49], torch.zeros(D, device=DEV, dtype=torch.bfloat16), img[0], img[11], wte[0],
+                       torch.zeros(D, device=DEV, dtype=torch.bfloat16)])
+    assert torch.equal(out, ref)
+    out2 = ops.gather_rows(wte, img, codes, D, out=out.clone(), accumulate=True)
+    assert relerr(out2, 2 * ref.float()) < 6e-3
+
+
+@pytest.mark.parametrize("rows,V", [(37, 512), (16, 128256)])
+def test_cross_entropy(rows, V):
+    logits = rnd(rows, V, seed=77, scale=3.0)
+    g = torch.Generator().manual_seed(78)
+    tgt = torch.randint(0, V, (rows,), generator=g)
+    tgt[::5] = -100
+    tgt_d = tgt.to(torch.int32).to(DEV)
+    acc = torch.zeros(2, device=DEV)
+    dl = torch.empty_like(logits)
+    ops.cross_entropy(logits, tgt_d, acc, dl)
+    lf = logits.float().requires_grad_(True)
+    ref = F.cross_entropy(lf, tgt.to(DEV), ignore_index=-100, reduction="sum")
+    ref.backward()
+    assert abs(acc[0].item() - ref.item()) < 1e-4 * abs(ref.item())
+    assert acc[1].item() == (tgt != -100).sum().item()
+    assert relerr(dl, lf.grad) < 8e-3
+    # in place
+    l2 = logits.clone()
+    ops.cross_entropy(l2, tgt_d, torch.zeros(2, device=DEV), l2)
+    assert torch.equal(l2, dl)
+
+
+def test_sumsq_adamw_f32tobf16():
+    n = 100003
+    p, g = rnd(n, seed=81), rnd(n, seed=82, scale=0.1)
+    m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    ss = torch.zeros(1, device=DEV)
+    ops.sumsq_(g, ss)
+    assert abs(ss.item() - (g.float() ** 2).sum().item()) < 1e-4 * ss.item()
+    pref = p.float().clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pref], lr=1e-2, betas=(0.9, 0.999), weight_decay=0.01)
+    p_cur = p.clone()
+    for step in (1, 2):
+        pref.grad = g.float().clone()
+        torch.nn.utils.clip_grad_norm_([pref], 1.0)
+        opt.step()
+        ops.adamw_step_(p_cur, g, m, v, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=step,
+                        max_norm=1.0, sumsq=ss)
+        if step == 1:
+            # bf16 parameter storage: one rounding of the updated value
+            assert (p_cur.float() - pref.detach()).abs().max().item() <= 2 ** -8 * pref.abs().max().item()
+    src = torch.randn(1000, device=DEV)
+    dst = rnd(1000, seed=83)
+    d0 = dst.clone()
+    ops.f32_to_bf16_(src, dst, scale=0.5, accumulate=True)
+    assert relerr(dst, d0.float() + 0.5 * src) < 6e-3

@@ -1,0 +1,63 @@
+"""ctypes binding of libzero_hip.so (the C ABI declared in include/zero_hip.h).
+
+There is NO fallback: if the library is missing the import fails loudly, so a GPU run can
+never silently route around the HIP kernels.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzero_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C zero_amd/csrc` (or __graft_entry__.build()); "
+        "zero_amd has no non-HIP fallback path")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+
+# name -> argtypes, in the order of include/zero_hip.h
+SIGNATURES = {
+    "zk_abi_version": [],
+    "zk_gemm_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _P, _P, _L, _P, _P, _L, _F, _P, _I, _P],
+    "zk_attn_fwd": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
+    "zk_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
+    "zk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _L, _F, _P],
+    "zk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P],
+    "zk_rmsnorm_fwd": [_P, _P, _P, _P, _L, _L, _F, _P],
+    "zk_rmsnorm_bwd": [_P, _P, _P, _P, _P, _P, _L, _L, _P],
+    "zk_rope": [_P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
+    "zk_swiglu_fwd": [_P, _P, _L, _L, _P],
+    "zk_swiglu_bwd": [_P, _P, _P, _L, _L, _P],
+    "zk_colsum": [_P, _P, _L, _L, _L, _P],
+    "zk_act_bwd": [_P, _P, _P, _L, _I, _P],
+    "zk_patch_im2col": [_P, _P, _L, _L, _L, _L, _L, _P],
+    "zk_embed_finish": [_P, _P, _P, _P, _L, _L, _L, _P],
+    "zk_gather_rows": [_P, _P, _P, _P, _L, _L, _I, _P],
+    "zk_cross_entropy": [_P, _P, _P, _P, _L, _L, _L, _P],
+    "zk_sumsq": [_P, _P, _L, _F, _P],
+    "zk_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P, _F, _P],
+    "zk_f32_to_bf16": [_P, _P, _L, _F, _I, _P],
+}
+
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here = header / library mismatch
+    _fn.argtypes = _args
+    _fn.restype = c_int
+
+ABI_VERSION = 1
+if lib.zk_abi_version() != ABI_VERSION:
+    raise ImportError("libzero_hip.so ABI version mismatch; rebuild with `make -C zero_amd/csrc`")
+
+
+class ZeroHipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise ZeroHipError(f"{what} failed with code {rc} "
+                           f"({'invalid argument / unsupported shape' if rc == -22 else 'launch failure'})")

@@ -1,0 +1,596 @@
+// Flash-style fused attention forward / backward for gfx950 (CDNA4), bf16 in, fp32 softmax.
+//
+// Replaces F.scaled_dot_product_attention (tf:integrations/sdpa_attention.py:154-163) for
+//   * the CLIP encoder: bidirectional, 16 heads x head_dim 64, T = 577 (tf:clip:317-330)
+//   * the Llama surrogate: causal, GQA (8 kv heads), head_dim 128 (tf:llama:264-277)
+// and its autograd backward.
+//
+// Layout idea (all three kernels): every product is a v_mfma_f32_32x32x16_bf16 whose
+// accumulator already IS the next product's operand, so the probabilities never travel
+// through LDS:
+//   fwd / dq : S^T[key][query] = K Q^T  -> query on the lane: row max / row sum / LSE / delta
+//              are per-lane scalars; P^T (resp. dS^T) is packed to bf16 in registers and
+//              used as the B operand of  O^T += V^T P^T  (resp. dQ^T += K^T dS^T).
+//   dkdv     : S[query][key] = Q K^T    -> key on the lane; P and dS are the B operands of
+//              dV^T += dO^T P and dK^T += Q^T dS.
+// The "transposed" A operands (V^T, K^T, dO^T, Q^T) are read from the row-major LDS tiles
+// with ds_read_b64_tr_b16.  An accumulator used as an operand has a permuted k order:
+// element j of lane-half h is row 16s + 8(j>>2) + 4h + (j&3) of k-step s; the tr reads
+// below fetch exactly those rows.
+// K/V (resp. Q/dO) tiles are double-buffered in LDS, staged HBM -> VGPR -> LDS with the
+// next tile's loads in flight during the MFMAs; one barrier per tile.
+// dQ is produced by its own pass (recomputing S and dP) instead of fp32 atomics: it is
+// deterministic, and attention is < 3 % of the step's FLOPs.
+#include "common.h"
+#include "../../include/zero_hip.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+struct AttnArgs {
+  const bf16_t *q, *k, *v, *o, *d_o;
+  bf16_t *out, *dq, *dk, *dv;
+  float* lse;
+  const float* lse_in;
+  const float* delta;
+  int B, S, Hq, Hkv;
+  int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+  float scale;
+};
+
+template <int HD>
+struct Cfg {
+  static constexpr int ROWB = HD * 2 + 16;   // LDS row stride in bytes (16-byte pad: conflict-free b128 row reads)
+  static constexpr int CPR = HD / 8;         // 16-byte chunks per row
+  static constexpr int DS = HD / 16;         // k-steps over the head dim
+  static constexpr int DB = HD / 32;         // 32-wide d blocks
+};
+
+// ---- staging helpers --------------------------------------------------------------------
+// Load ROWS x HD tile (rows of `ld` elements starting at `base`, valid rows < nvalid) into regs.
+template <int HD, int ROWS>
+__device__ __forceinline__ void tile_gload(u32x4 (&r)[ROWS * HD / 8 / 256], const bf16_t* base, int ld, int nvalid,
+                                           int tid) {
+  constexpr int N = ROWS * HD / 8 / 256;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    int c = tid + 256 * i;
+    int row = c / Cfg<HD>::CPR, ch = c % Cfg<HD>::CPR;
+    if (row < nvalid) r[i] = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + ch * 8);
+    else r[i] = u32x4{0u, 0u, 0u, 0u};
+  }
+}
+template <int HD, int ROWS>
+__device__ __forceinline__ void tile_lstore(const u32x4 (&r)[ROWS * HD / 8 / 256], unsigned char* lds, int tid) {
+  constexpr int N = ROWS * HD / 8 / 256;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    int c = tid + 256 * i;
+    int row = c / Cfg<HD>::CPR, ch = c % Cfg<HD>::CPR;
+    *reinterpret_cast<u32x4*>(lds + row * Cfg<HD>::ROWB + ch * 16) = r[i];
+  }
+}
+// MFMA 32x32x16 A/B row fragment: tile row (row0 + lane&31), d = ds*16 + 8*(lane>>5) .. +7
+template <int HD>
+__device__ __forceinline__ bf16x8 row_frag(const unsigned char* lds, int row0, int ds, int lane) {
+  return *reinterpret_cast<const bf16x8*>(lds + (row0 + (lane & 31)) * Cfg<HD>::ROWB + (ds * 16 + 8 * (lane >> 5)) * 2);
+}
+// Transposed A fragment: element j <-> tile row (k0 + 16s + 8(j>>2) + 4h + (j&3)), A-row = column (db*32 + lane&31)
+template <int HD>
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lds, int k0, int s, int db, int lane) {
+  const int h = lane >> 5, i = lane & 15;
+  const int row = k0 + 16 * s + 4 * h + (i >> 2);
+  const int col = db * 32 + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+  const unsigned char* p = lds + row * Cfg<HD>::ROWB + col * 2;
+  short4_t lo = lds_read_tr16(p);
+  short4_t hi = lds_read_tr16(p + 8 * Cfg<HD>::ROWB);
+  union { struct { short4_t a, b; } s2; bf16x8 v; } u;
+  u.s2.a = lo;
+  u.s2.b = hi;
+  return u.v;
+}
+__device__ __forceinline__ bf16x8 pack_acc(const f32x16& a, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * s + j];
+  return r;
+}
+__device__ __forceinline__ bf16x8 gfrag(const bf16_t* p, bool ok) {
+  if (!ok) { bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f; return z; }
+  return *reinterpret_cast<const bf16x8*>(p);
+}
+// accumulator register r of lane-half h <-> tile row
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// =========================================================================================
+// forward
+// =========================================================================================
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  using C = Cfg<HD>;
+  constexpr int KV = 64;
+  constexpr int TILE = KV * C::ROWB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];  // [buf][K|V]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int qblk = gridDim.x - 1 - blockIdx.x;  // heaviest (causal) blocks first
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int kvh = head / (a.Hq / a.Hkv);
+  const int q0 = qblk * 128 + wave * 32;
+  const int qi = q0 + (lane & 31);
+  const float sc = a.scale * LOG2E;
+
+  const bf16_t* kbase = a.k + (size_t)b * a.S * a.ldk + kvh * HD;
+  const bf16_t* vbase = a.v + (size_t)b * a.S * a.ldv + kvh * HD;
+  bf16x8 qf[C::DS];
+  {
+    const bf16_t* qp = a.q + ((size_t)b * a.S + qi) * a.ldq + head * HD + 8 * h;
+#pragma unroll
+    for (int ds = 0; ds < C::DS; ++ds) qf[ds] = gfrag(qp + ds * 16, qi < a.S);
+  }
+  int kv_end = a.S;
+  if (CAUSAL) kv_end = min(a.S, qblk * 128 + 128);
+  const int nt = (kv_end + KV - 1) / KV;
+  int nt_wave = nt;
+  if (CAUSAL) nt_wave = min(nt, (q0 + 32 + KV - 1) / KV);
+
+  f32x16 o[C::DB];
+#pragma unroll
+  for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  constexpr int NR = KV * HD / 8 / 256;
+  u32x4 rk[NR], rv[NR];
+  tile_gload<HD, KV>(rk, kbase, a.ldk, a.S, tid);
+  tile_gload<HD, KV>(rv, vbase, a.ldv, a.S, tid);
+  tile_lstore<HD, KV>(rk, smem, tid);
+  tile_lstore<HD, KV>(rv, smem + TILE, tid);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const unsigned char* kl = smem + (t & 1) * 2 * TILE;
+    const unsigned char* vl = kl + TILE;
+    const bool more = t + 1 < nt;
+    if (more) {
+      const int kn = (t + 1) * KV;
+      tile_gload<HD, KV>(rk, kbase + (size_t)kn * a.ldk, a.ldk, a.S - kn, tid);
+      tile_gload<HD, KV>(rv, vbase + (size_t)kn * a.ldv, a.ldv, a.S - kn, tid);
+    }
+    if (t < nt_wave) {
+      const int k0 = t * KV;
+      f32x16 s[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+        for (int ds = 0; ds < C::DS; ++ds)
+          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(kl, kb * 32, ds, lane), qf[ds], s[kb], 0, 0, 0);
+      }
+      const bool need_mask = (k0 + KV > a.S) || (CAUSAL && (k0 + KV - 1 > q0));
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float val = s[kb][r] * sc;
+          if (need_mask) {
+            int key = k0 + kb * 32 + acc_row(r, h);
+            if (key >= a.S || (CAUSAL && key > qi)) val = -INFINITY;
+          }
+          s[kb][r] = val;
+          mx = fmaxf(mx, val);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = fast_exp2(m_run - m_use);
+      float rs = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float p = fast_exp2(s[kb][r] - m_use);
+          s[kb][r] = p;
+          rs += p;
+        }
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          bf16x8 pf = pack_acc(s[kb], st);
+#pragma unroll
+          for (int d = 0; d < C::DB; ++d)
+            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(vl, kb * 32, st, d, lane), pf, o[d], 0, 0, 0);
+        }
+    }
+    if (more) {
+      unsigned char* nx = smem + ((t + 1) & 1) * 2 * TILE;
+      tile_lstore<HD, KV>(rk, nx, tid);
+      tile_lstore<HD, KV>(rv, nx + TILE, tid);
+    }
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
+  if (qi < a.S) {
+    bf16_t* op = a.out + ((size_t)b * a.S + qi) * a.ldo + head * HD;
+#pragma unroll
+    for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        u32x2 w;
+        w[0] = pack2bf(o[d][4 * r4] * inv, o[d][4 * r4 + 1] * inv);
+        w[1] = pack2bf(o[d][4 * r4 + 2] * inv, o[d][4 * r4 + 3] * inv);
+        *reinterpret_cast<u32x2*>(op + d * 32 + 8 * r4 + 4 * h) = w;
+      }
+    if (h == 0 && a.lse) a.lse[((size_t)b * a.Hq + head) * a.S + qi] = m_run * LN2 + logf(l_tot);
+  }
+}
+
+// =========================================================================================
+// backward: delta = rowsum(dO * O)
+// =========================================================================================
+template <int HD>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* o, const bf16_t* d_o, float* delta, int B, int S,
+                                                         int Hq, int ldo) {
+  constexpr int LPR = HD / 8;  // lanes per (token, head)
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t item = gid / LPR;
+  const int c = (int)(gid % LPR);
+  const int64_t total = (int64_t)B * S * Hq;
+  float acc = 0.f;
+  int64_t tok = 0; int head = 0;
+  if (item < total) {
+    tok = item / Hq; head = (int)(item % Hq);
+    const size_t off = (size_t)tok * ldo + head * HD + c * 8;
+    u32x4 x = *reinterpret_cast<const u32x4*>(o + off);
+    u32x4 y = *reinterpret_cast<const u32x4*>(d_o + off);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc += lo_bf(x[j]) * lo_bf(y[j]) + hi_bf(x[j]) * hi_bf(y[j]);
+  }
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (item < total && c == 0) {
+    int64_t bb = tok / S, s = tok % S;
+    delta[(bb * Hq + head) * S + s] = acc;
+  }
+}
+
+// =========================================================================================
+// backward: dQ  (per 128-query block, sweep over key tiles)
+// =========================================================================================
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+  using C = Cfg<HD>;
+  constexpr int KV = 64;
+  constexpr int TILE = KV * C::ROWB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int qblk = gridDim.x - 1 - blockIdx.x;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int kvh = head / (a.Hq / a.Hkv);
+  const int q0 = qblk * 128 + wave * 32;
+  const int qi = q0 + (lane & 31);
+  const float sc = a.scale * LOG2E;
+  const bool qok = qi < a.S;
+
+  const bf16_t* kbase = a.k + (size_t)b * a.S * a.ldk + kvh * HD;
+  const bf16_t* vbase = a.v + (size_t)b * a.S * a.ldv + kvh * HD;
+  bf16x8 qf[C::DS], dof[C::DS];
+  {
+    const bf16_t* qp = a.q + ((size_t)b * a.S + qi) * a.ldq + head * HD + 8 * h;
+    const bf16_t* dp = a.d_o + ((size_t)b * a.S + qi) * a.ldo + head * HD + 8 * h;
+#pragma unroll
+    for (int ds = 0; ds < C::DS; ++ds) { qf[ds] = gfrag(qp + ds * 16, qok); dof[ds] = gfrag(dp + ds * 16, qok); }
+  }
+  const size_t stat = ((size_t)b * a.Hq + head) * a.S + (qok ? qi : 0);
+  const float lse2 = qok ? a.lse_in[stat] * LOG2E : 0.f;
+  const float dlt = qok ? a.delta[stat] : 0.f;
+
+  int kv_end = a.S;
+  if (CAUSAL) kv_end = min(a.S, qblk * 128 + 128);
+  const int nt = (kv_end + KV - 1) / KV;
+  int nt_wave = nt;
+  if (CAUSAL) nt_wave = min(nt, (q0 + 32 + KV - 1) / KV);
+
+  f32x16 dq[C::DB];
+#pragma unroll
+  for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+
+  constexpr int NR = KV * HD / 8 / 256;
+  u32x4 rk[NR], rv[NR];
+  tile_gload<HD, KV>(rk, kbase, a.ldk, a.S, tid);
+  tile_gload<HD, KV>(rv, vbase, a.ldv, a.S, tid);
+  tile_lstore<HD, KV>(rk, smem, tid);
+  tile_lstore<HD, KV>(rv, smem + TILE, tid);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const unsigned char* kl = smem + (t & 1) * 2 * TILE;
+    const unsigned char* vl = kl + TILE;
+    const bool more = t + 1 < nt;
+    if (more) {
+      const int kn = (t + 1) * KV;
+      tile_gload<HD, KV>(rk, kbase + (size_t)kn * a.ldk, a.ldk, a.S - kn, tid);
+      tile_gload<HD, KV>(rv, vbase + (size_t)kn * a.ldv, a.ldv, a.S - kn, tid);
+    }
+    if (t < nt_wave) {
+      const int k0 = t * KV;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ds = 0; ds < C::DS; ++ds) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(kl, kb * 32, ds, lane), qf[ds], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(vl, kb * 32, ds, lane), dof[ds], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int key = k0 + kb * 32 + acc_row(r, h);
+          float p = fast_exp2(s[r] * sc - lse2);
+          if (key >= a.S || !qok || (CAUSAL && key > qi)) p = 0.f;
+          s[r] = p * (dp[r] - dlt);   // dS^T (without the softmax scale)
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          bf16x8 df = pack_acc(s, st);
+#pragma unroll
+          for (int d = 0; d < C::DB; ++d)
+            dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(kl, kb * 32, st, d, lane), df, dq[d], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      unsigned char* nx = smem + ((t + 1) & 1) * 2 * TILE;
+      tile_lstore<HD, KV>(rk, nx, tid);
+      tile_lstore<HD, KV>(rv, nx + TILE, tid);
+    }
+    __syncthreads();
+  }
+  if (qok) {
+    bf16_t* op = a.dq + ((size_t)b * a.S + qi) * a.lddq + head * HD;
+#pragma unroll
+    for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        u32x2 w;
+        w[0] = pack2bf(dq[d][4 * r4] * a.scale, dq[d][4 * r4 + 1] * a.scale);
+        w[1] = pack2bf(dq[d][4 * r4 + 2] * a.scale, dq[d][4 * r4 + 3] * a.scale);
+        *reinterpret_cast<u32x2*>(op + d * 32 + 8 * r4 + 4 * h) = w;
+      }
+  }
+}
+
+// =========================================================================================
+// backward: dK, dV  (per 128-key block of one kv head, sweep over its q heads x query tiles)
+// =========================================================================================
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
+  using C = Cfg<HD>;
+  constexpr int QT = 32;
+  constexpr int TILE = QT * C::ROWB;
+  constexpr int STAGE = 2 * TILE + 256;  // Q tile, dO tile, lse2[32], delta[32]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int kblk = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+  const int rep = a.Hq / a.Hkv;
+  const int k0w = kblk * 128 + wave * 32;
+  const int ki = k0w + (lane & 31);
+  const bool kok = ki < a.S;
+  const float sc = a.scale * LOG2E;
+
+  bf16x8 kf[C::DS], vf[C::DS];
+  {
+    const bf16_t* kp = a.k + ((size_t)b * a.S + ki) * a.ldk + kvh * HD + 8 * h;
+    const bf16_t* vp = a.v + ((size_t)b * a.S + ki) * a.ldv + kvh * HD + 8 * h;
+#pragma unroll
+    for (int ds = 0; ds < C::DS; ++ds) { kf[ds] = gfrag(kp + ds * 16, kok); vf[ds] = gfrag(vp + ds * 16, kok); }
+  }
+  f32x16 dk[C::DB], dv[C::DB];
+#pragma unroll
+  for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+
+  const int nqt_all = (a.S + QT - 1) / QT;
+  const int qt0 = CAUSAL ? (kblk * 128) / QT : 0;   // queries before the block's first key see none of it
+  const int nqt = nqt_all - qt0;
+  const int niter = rep * nqt;
+
+  constexpr int NR = (QT * HD / 8 + 255) / 256;   // 2 for HD=128, 1 for HD=64
+  u32x4 rq[NR], rdo[NR];
+  float rl = 0.f, rd = 0.f;
+  auto issue = [&](int it) {
+    const int hq = kvh * rep + it / nqt;
+    const int qb = (qt0 + it % nqt) * QT;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      int c = tid + 256 * i;
+      int row = c / C::CPR, ch = c % C::CPR;
+      bool ok = (c < QT * C::CPR) && (qb + row < a.S);
+      if (ok) {
+        rq[i] = *reinterpret_cast<const u32x4*>(a.q + ((size_t)b * a.S + qb + row) * a.ldq + hq * HD + ch * 8);
+        rdo[i] = *reinterpret_cast<const u32x4*>(a.d_o + ((size_t)b * a.S + qb + row) * a.ldo + hq * HD + ch * 8);
+      } else { rq[i] = u32x4{0u, 0u, 0u, 0u}; rdo[i] = u32x4{0u, 0u, 0u, 0u}; }
+    }
+    if (tid < QT) {
+      bool ok = qb + tid < a.S;
+      size_t st = ((size_t)b * a.Hq + hq) * a.S + qb + (ok ? tid : 0);
+      rl = ok ? a.lse_in[st] * LOG2E : 0.f;
+      rd = ok ? a.delta[st] : 0.f;
+    }
+  };
+  auto commit = [&](unsigned char* st) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      int c = tid + 256 * i;
+      if (c < QT * C::CPR) {
+        int row = c / C::CPR, ch = c % C::CPR;
+        *reinterpret_cast<u32x4*>(st + row * C::ROWB + ch * 16) = rq[i];
+        *reinterpret_cast<u32x4*>(st + TILE + row * C::ROWB + ch * 16) = rdo[i];
+      }
+    }
+    if (tid < QT) {
+      reinterpret_cast<float*>(st + 2 * TILE)[tid] = rl;
+      reinterpret_cast<float*>(st + 2 * TILE + 128)[tid] = rd;
+    }
+  };
+
+  if (niter > 0) { issue(0); commit(smem); }
+  __syncthreads();
+
+  for (int it = 0; it < niter; ++it) {
+    const unsigned char* st = smem + (it & 1) * STAGE;
+    const unsigned char* ql = st;
+    const unsigned char* dol = st + TILE;
+    const float* lsl = reinterpret_cast<const float*>(st + 2 * TILE);
+    const float* dll = reinterpret_cast<const float*>(st + 2 * TILE + 128);
+    const bool more = it + 1 < niter;
+    if (more) issue(it + 1);
+    const int qb = (qt0 + it % nqt) * QT;
+    // causal: this wave's keys are all after the tile's last query -> nothing to do
+    const bool skip = CAUSAL && (k0w > qb + QT - 1);
+    if (!skip) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ds = 0; ds < C::DS; ++ds) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(ql, 0, ds, lane), kf[ds], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(dol, 0, ds, lane), vf[ds], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsl + 8 * r4 + 4 * h);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(dll + 8 * r4 + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * r4 + e;
+          const int qidx = qb + 8 * r4 + 4 * h + e;
+          float p = fast_exp2(s[r] * sc - l4[e]);
+          if (!kok || qidx >= a.S || (CAUSAL && ki > qidx)) p = 0.f;
+          s[r] = p;
+          dp[r] = p * (dp[r] - d4[e]);
+        }
+      }
+#pragma unroll
+      for (int stp = 0; stp < 2; ++stp) {
+        bf16x8 pf = pack_acc(s, stp);
+        bf16x8 df = pack_acc(dp, stp);
+#pragma unroll
+        for (int d = 0; d < C::DB; ++d) {
+          dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(dol, 0, stp, d, lane), pf, dv[d], 0, 0, 0);
+          dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(ql, 0, stp, d, lane), df, dk[d], 0, 0, 0);
+        }
+      }
+    }
+    if (more) commit(smem + ((it + 1) & 1) * STAGE);
+    __syncthreads();
+  }
+
+  if (kok) {
+    bf16_t* kp = a.dk + ((size_t)b * a.S + ki) * a.lddk + kvh * HD;
+    bf16_t* vp = a.dv + ((size_t)b * a.S + ki) * a.lddv + kvh * HD;
+#pragma unroll
+    for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        u32x2 w;
+        w[0] = pack2bf(dk[d][4 * r4] * a.scale, dk[d][4 * r4 + 1] * a.scale);
+        w[1] = pack2bf(dk[d][4 * r4 + 2] * a.scale, dk[d][4 * r4 + 3] * a.scale);
+        *reinterpret_cast<u32x2*>(kp + d * 32 + 8 * r4 + 4 * h) = w;
+        w[0] = pack2bf(dv[d][4 * r4], dv[d][4 * r4 + 1]);
+        w[1] = pack2bf(dv[d][4 * r4 + 2], dv[d][4 * r4 + 3]);
+        *reinterpret_cast<u32x2*>(vp + d * 32 + 8 * r4 + 4 * h) = w;
+      }
+  }
+}
+
+bool bad_attn(int64_t B, int64_t S, int64_t Hq, int64_t Hkv, int64_t hd, int64_t l0, int64_t l1, int64_t l2, int64_t l3) {
+  if (B <= 0 || S <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv) return true;
+  if (hd != 64 && hd != 128) return true;
+  if ((l0 | l1 | l2 | l3) & 7) return true;
+  if (B > 65535 || Hq > 65535) return true;
+  return false;
+}
+
+}  // namespace
+
+extern "C" int zk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B, int64_t S,
+                           int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv,
+                           int64_t ldo, float scale, int causal, hipStream_t stream) {
+  if (!q || !k || !v || !o || bad_attn(B, S, Hq, Hkv, head_dim, ldq, ldk, ldv, ldo)) return ZK_EINVAL;
+  AttnArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
+  a.B = (int)B; a.S = (int)S; a.Hq = (int)Hq; a.Hkv = (int)Hkv;
+  a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv; a.ldo = (int)ldo; a.scale = scale;
+  dim3 grid((unsigned)((S + 127) / 128), (unsigned)Hq, (unsigned)B), block(256);
+  if (head_dim == 64) {
+    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, block, 0, stream, a);
+  } else {
+    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, block, 0, stream, a);
+  }
+  ZK_CHECK_LAUNCH();
+  return ZK_OK;
+}
+
+extern "C" int zk_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                           const float* lse, float* delta, void* dq, void* dk, void* dv, int64_t B, int64_t S,
+                           int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv,
+                           int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal,
+                           hipStream_t stream) {
+  if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv) return ZK_EINVAL;
+  if (bad_attn(B, S, Hq, Hkv, head_dim, ldq, ldk, ldv, ldo) || ((lddq | lddk | lddv) & 7)) return ZK_EINVAL;
+  AttnArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
+  a.d_o = (const bf16_t*)d_o; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+  a.lse_in = lse; a.delta = delta;
+  a.B = (int)B; a.S = (int)S; a.Hq = (int)Hq; a.Hkv = (int)Hkv;
+  a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv; a.ldo = (int)ldo;
+  a.lddq = (int)lddq; a.lddk = (int)lddk; a.lddv = (int)lddv; a.scale = scale;
+  const int64_t items = B * S * Hq * (head_dim / 8);
+  dim3 gd((unsigned)((items + 255) / 256)), block(256);
+  dim3 gq((unsigned)((S + 127) / 128), (unsigned)Hq, (unsigned)B);
+  dim3 gk((unsigned)((S + 127) / 128), (unsigned)Hkv, (unsigned)B);
+  if (head_dim == 64) {
+    hipLaunchKernelGGL((attn_delta_kernel<64>), gd, block, 0, stream, a.o, a.d_o, delta, a.B, a.S, a.Hq, a.ldo);
+    if (causal) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, block, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, true>), gk, block, 0, stream, a);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false>), gq, block, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, false>), gk, block, 0, stream, a);
+    }
+  } else {
+    hipLaunchKernelGGL((attn_delta_kernel<128>), gd, block, 0, stream, a.o, a.d_o, delta, a.B, a.S, a.Hq, a.ldo);
+    if (causal) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), gq, block, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, true>), gk, block, 0, stream, a);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<128, false>), gq, block, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false>), gk, block, 0, stream, a);
+    }
+  }
+  ZK_CHECK_LAUNCH();
+  return ZK_OK;
+}

@@ -1,0 +1,68 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of zero_amd.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits in HBM
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define ZK_OK 0
+#define ZK_EINVAL (-22)
+#define ZK_ELAUNCH (-5)
+
+#define ZK_CHECK_LAUNCH()                                   \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return ZK_ELAUNCH;               \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) {
+  return __uint_as_float(((unsigned int)v) << 16);
+}
+// round-to-nearest-even through the hardware convert (keeps NaN a NaN)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return *reinterpret_cast<unsigned int*>(&v);
+}
+__device__ __forceinline__ float lo_bf(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi_bf(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// 16-byte global load through a buffer descriptor; out-of-range offsets return 0.
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned int byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// LDS transposed read: per 16-lane group a 4(row) x 16(col) block of 16-bit elements; the lane
+// 4q+p supplies the address of row q, cols 4p..4p+3; lane i receives column i, rows 0..3.
+__device__ __forceinline__ short4_t lds_read_tr16(const void* lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) short4_t*)(lds_addr));
+}

@@ -1,0 +1,261 @@
+"""Tensor-level wrappers over the C ABI (include/zero_hip.h).
+
+PyTorch is used here for device memory and streams only; every arithmetic op below is a
+hand-written gfx950 kernel in libzero_hip.so.  All tensors are bf16 on a ROCm device unless
+stated; 2-D operands may be row-strided views (stride(1) == 1), so column slices of packed
+buffers are passed without copies.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ._lib import check, lib
+
+EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_MUL_DQUICK_GELU, EPI_MUL_DGELU_ERF = 0, 1, 2, 3, 4
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk2d(t: torch.Tensor, name: str, dtype=BF16):
+    if not t.is_cuda:
+        raise ValueError(f"{name}: zero_amd kernels need a ROCm device tensor (no CPU path exists)")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected a 2-D row-major view, got shape {tuple(t.shape)} strides {t.stride()}")
+
+
+def _chk_flat(t: torch.Tensor, name: str, dtype=BF16):
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous {dtype} ROCm tensor")
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
+         out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+         residual: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
+         aux_out: Optional[torch.Tensor] = None, aux_in: Optional[torch.Tensor] = None,
+         alpha: float = 1.0, alpha_dev: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """C[m,n] = epi(alpha * sum_k A(m,k) B(n,k)).  a: [M,K] (or [K,M] if trans_a); b: [N,K] (or [K,N] if trans_b)."""
+    _chk2d(a, "a"); _chk2d(b, "b")
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    N, Kb = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    if K != Kb:
+        raise ValueError(f"gemm: contraction mismatch {K} vs {Kb}")
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    _chk2d(out, "out")
+    if out.shape != (M, N):
+        raise ValueError(f"gemm: out shape {tuple(out.shape)} != {(M, N)}")
+    if bias is not None:
+        _chk_flat(bias, "bias")
+        if bias.numel() != N:
+            raise ValueError("gemm: bias size")
+    ldr = 0
+    if residual is not None:
+        _chk2d(residual, "residual")
+        if residual.shape != (M, N):
+            raise ValueError("gemm: residual shape")
+        ldr = residual.stride(0)
+    if aux_out is not None:
+        _chk2d(aux_out, "aux_out")
+        if aux_out.shape != (M, N) or aux_out.stride(0) != out.stride(0):
+            raise ValueError("gemm: aux_out must match out's shape and row stride")
+    ldaux = 0
+    if aux_in is not None:
+        _chk2d(aux_in, "aux_in")
+        if aux_in.shape != (M, N):
+            raise ValueError("gemm: aux_in shape")
+        ldaux = aux_in.stride(0)
+    if alpha_dev is not None:
+        _chk_flat(alpha_dev, "alpha_dev", torch.float32)
+    rc = lib.zk_gemm_bf16(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+                          int(trans_a), int(trans_b), epilogue, _p(bias), _p(residual), ldr, _p(aux_out),
+                          _p(aux_in), ldaux, float(alpha), _p(alpha_dev), int(accumulate), _stream())
+    check(rc, f"zk_gemm_bf16 M={M} N={N} K={K} tA={trans_a} tB={trans_b}")
+    return out
+
+
+def attn_fwd(q, k, v, B: int, S: int, Hq: int, Hkv: int, hd: int, scale: float, causal: bool,
+             out: Optional[torch.Tensor] = None, need_lse: bool = True):
+    """q/k/v: [B*S, H*hd] row-strided views.  Returns (o [B*S, Hq*hd], lse [B,Hq,S] fp32 or None)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk2d(t, n)
+    if q.shape != (B * S, Hq * hd) or k.shape != (B * S, Hkv * hd) or v.shape != (B * S, Hkv * hd):
+        raise ValueError("attn_fwd: q/k/v shapes")
+    if out is None:
+        out = torch.empty((B * S, Hq * hd), dtype=BF16, device=q.device)
+    _chk2d(out, "out")
+    lse = torch.empty((B, Hq, S), dtype=torch.float32, device=q.device) if need_lse else None
+    rc = lib.zk_attn_fwd(_p(q), _p(k), _p(v), _p(out), _p(lse), B, S, Hq, Hkv, hd, q.stride(0), k.stride(0),
+                         v.stride(0), out.stride(0), float(scale), int(causal), _stream())
+    check(rc, "zk_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B: int, S: int, Hq: int, Hkv: int, hd: int, scale: float,
+             causal: bool):
+    """Writes dq/dk/dv (row-strided views, may be slices of one packed d_qkv buffer)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (d_o, "d_o"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        _chk2d(t, n)
+    if o.stride(0) != d_o.stride(0):
+        raise ValueError("attn_bwd: o and d_o must share a row stride")
+    _chk_flat(lse, "lse", torch.float32)
+    delta = torch.empty_like(lse)
+    rc = lib.zk_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, S, Hq,
+                         Hkv, hd, q.stride(0), k.stride(0), v.stride(0), o.stride(0), dq.stride(0), dk.stride(0),
+                         dv.stride(0), float(scale), int(causal), _stream())
+    check(rc, "zk_attn_bwd")
+
+
+def layernorm_fwd(x, gamma, beta, eps: float, save_stats: bool = True):
+    _chk2d(x, "x"); _chk_flat(gamma, "gamma"); _chk_flat(beta, "beta")
+    if not x.is_contiguous():
+        raise ValueError("layernorm: x must be contiguous")
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    check(lib.zk_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D, float(eps), _stream()),
+          "zk_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, need_dx: bool = True):
+    """dx = dres + LN'(dy); dgamma/dbeta (fp32 [D]) are accumulated into when given."""
+    _chk2d(dy, "dy"); _chk2d(x, "x")
+    if not (dy.is_contiguous() and x.is_contiguous()):
+        raise ValueError("layernorm_bwd: contiguous inputs required")
+    rows, D = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    if dres is not None and not dres.is_contiguous():
+        raise ValueError("layernorm_bwd: dres must be contiguous")
+    check(lib.zk_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dgamma), _p(dbeta),
+                               rows, D, _stream()), "zk_layernorm_bwd")
+    return dx
+
+
+def rmsnorm_fwd(x, w, eps: float, save_stats: bool = True):
+    _chk2d(x, "x"); _chk_flat(w, "w")
+    if not x.is_contiguous():
+        raise ValueError("rmsnorm: x must be contiguous")
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    check(lib.zk_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), rows, D, float(eps), _stream()), "zk_rmsnorm_fwd")
+    return y, rstd
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dres=None):
+    _chk2d(dy, "dy"); _chk2d(x, "x")
+    if not (dy.is_contiguous() and x.is_contiguous()) or (dres is not None and not dres.is_contiguous()):
+        raise ValueError("rmsnorm_bwd: contiguous inputs required")
+    rows, D = x.shape
+    dx = torch.empty_like(x)
+    check(lib.zk_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), rows, D, _stream()), "zk_rmsnorm_bwd")
+    return dx
+
+
+def rope_(x2d, cos_t, sin_t, S: int, heads: int, hd: int, inverse: bool = False):
+    """In place on the first `heads*hd` columns of the row-strided view x2d."""
+    _chk2d(x2d, "x")
+    _chk_flat(cos_t, "cos", torch.float32); _chk_flat(sin_t, "sin", torch.float32)
+    if cos_t.shape[0] < S or cos_t.shape[1] != hd // 2:
+        raise ValueError("rope: table shape")
+    check(lib.zk_rope(_p(x2d), _p(cos_t), _p(sin_t), x2d.shape[0], S, heads, hd, x2d.stride(0), int(inverse),
+                      _stream()), "zk_rope")
+    return x2d
+
+
+def swiglu_fwd(gu, F: int):
+    _chk2d(gu, "gu")
+    if not gu.is_contiguous() or gu.shape[1] != 2 * F:
+        raise ValueError("swiglu_fwd: gu must be contiguous [rows, 2F]")
+    h = torch.empty((gu.shape[0], F), dtype=BF16, device=gu.device)
+    check(lib.zk_swiglu_fwd(_p(gu), _p(h), gu.shape[0], F, _stream()), "zk_swiglu_fwd")
+    return h
+
+
+def swiglu_bwd(dh, gu, F: int):
+    _chk2d(dh, "dh"); _chk2d(gu, "gu")
+    if not (dh.is_contiguous() and gu.is_contiguous()):
+        raise ValueError("swiglu_bwd: contiguous inputs required")
+    dgu = torch.empty_like(gu)
+    check(lib.zk_swiglu_bwd(_p(dh), _p(gu), _p(dgu), gu.shape[0], F, _stream()), "zk_swiglu_bwd")
+    return dgu
+
+
+def colsum_(dy, out_f32):
+    _chk2d(dy, "dy"); _chk_flat(out_f32, "out", torch.float32)
+    check(lib.zk_colsum(_p(dy), _p(out_f32), dy.shape[0], dy.shape[1], dy.stride(0), _stream()), "zk_colsum")
+    return out_f32
+
+
+def act_bwd(dy, pre, kind: int, out=None):
+    if not (dy.is_contiguous() and pre.is_contiguous()):
+        raise ValueError("act_bwd: contiguous inputs required")
+    if out is None:
+        out = torch.empty_like(dy)
+    check(lib.zk_act_bwd(_p(dy), _p(pre), _p(out), dy.numel(), kind, _stream()), "zk_act_bwd")
+    return out
+
+
+def patch_im2col(pixels, P: int, Kpad: int):
+    if pixels.dtype != BF16 or not pixels.is_contiguous() or pixels.dim() != 4 or pixels.shape[1] != 3:
+        raise ValueError("patch_im2col: pixels must be contiguous bf16 [B,3,H,W]")
+    B, _, H, W = pixels.shape
+    cols = torch.empty((B * (H // P) * (W // P), Kpad), dtype=BF16, device=pixels.device)
+    check(lib.zk_patch_im2col(_p(pixels), _p(cols), B, H, W, P, Kpad, _stream()), "zk_patch_im2col")
+    return cols
+
+
+def embed_finish(patch, cls, pos, B: int, T: int, D: int):
+    out = torch.empty((B, T, D), dtype=BF16, device=patch.device)
+    check(lib.zk_embed_finish(_p(patch), _p(cls), _p(pos), _p(out), B, T, D, _stream()), "zk_embed_finish")
+    return out
+
+
+def gather_rows(table0, table1, codes, D: int, out=None, accumulate: bool = False):
+    """out[r] = table0[code] (code>=0) | 0 (code==-1) | table1[-2-code] (code<=-2)."""
+    if codes.dtype != torch.int32 or not codes.is_contiguous():
+        raise ValueError("gather_rows: codes must be contiguous int32")
+    rows = codes.numel()
+    if out is None:
+        out = torch.empty((rows, D), dtype=BF16, device=codes.device)
+    check(lib.zk_gather_rows(_p(table0), _p(table1), _p(codes), _p(out), rows, D, int(accumulate), _stream()),
+          "zk_gather_rows")
+    return out
+
+
+def cross_entropy(logits, targets_i32, loss_acc, dlogits=None):
+    """loss_acc (fp32[2]) += [sum of row losses, number of non-ignored rows]."""
+    _chk2d(logits, "logits")
+    rows, V = logits.shape
+    check(lib.zk_cross_entropy(_p(logits), _p(targets_i32), _p(loss_acc), _p(dlogits), rows, V, logits.stride(0),
+                               _stream()), "zk_cross_entropy")
+    return loss_acc
+
+
+def sumsq_(g_flat, out_f32, scale: float = 1.0):
+    check(lib.zk_sumsq(_p(g_flat), _p(out_f32), g_flat.numel(), float(scale), _stream()), "zk_sumsq")
+    return out_f32
+
+
+def adamw_step_(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max_norm, sumsq, grad_scale=1.0):
+    check(lib.zk_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                            float(weight_decay), int(step), float(max_norm), _p(sumsq), float(grad_scale), _stream()),
+          "zk_adamw_step")
+
+
+def f32_to_bf16_(src, dst, scale: float = 1.0, accumulate: bool = False):
+    check(lib.zk_f32_to_bf16(_p(src), _p(dst), src.numel(), float(scale), int(accumulate), _stream()),
+          "zk_f32_to_bf16")
+    return dst
