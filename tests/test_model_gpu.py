@@ -1,0 +1,201 @@
+"""End-to-end parity of the HIP path against (a) the golden vectors produced by the real
+transformers modules + the reference's Zero (tests/golden/*.safetensors) and (b) the fp32
+CPU oracle run live on the same seeded inputs.
+
+Tolerance (north_star: "within a stated bf16 tolerance, e.g. max rel 1e-2"):
+  * loss: |dloss| <= 1e-2 absolute and relative;
+  * tensors (logits, inputs_embeds, hidden states): max|a-b| / max|b| <= 2e-2  — bf16 has
+    2^-8 = 3.9e-3 resolution per rounding and the path rounds after every op through 4..20
+    layers; the transformers bf16 run itself sits at ~0.5-1e-2 from its fp32 run on these
+    configs (checked below: the HIP path must be no further from fp32 than 2x that + 5e-3);
+  * parameter gradients: ||g - g_ref|| / ||g_ref|| <= 3e-2 per tensor (Frobenius), per rank
+    before the all-reduce.
+"""
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from oracle import zero_oracle as zo
+from tests.golden.configs import GOLDEN_CONFIGS, shrink
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def maxrel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+def normrel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def grad_err(g, g_ref, scale):
+    """Frobenius error relative to the reference gradient; a gradient that is analytically
+    zero (k_proj.bias: a constant added to every key shifts all scores of a query equally) is
+    judged against the size of the other gradients instead of its own rounding noise."""
+    g, g_ref = g.float().cpu(), g_ref.float().cpu()
+    return ((g - g_ref).norm() / max(g_ref.norm().item(), 1e-3 * scale)).item()
+
+
+def run_hip(spec, params, imgs, ids, tgts, img_id, pad_id):
+    from tests.helpers import build_model, make_cfg
+    from zero_amd.configs.zero.train_llama import func_optim_filter
+    from zero_amd.methods.engine_ar_instruction_llama import forward_from_ids
+    cfg = make_cfg(spec["enc"], spec["dec"], DEV, spec["ft_after"], spec["max_seq_len"])
+    model = build_model(cfg, params)
+    func_optim_filter(cfg, model)
+    model.train()
+    dimgs = [i.to(DEV).to(torch.bfloat16) for i in imgs]
+    loss, aux = forward_from_ids(model, cfg, dimgs, ids, tgts, img_id, pad_id, return_aux=True)
+    aux["inputs_embeds"].retain_grad()
+    loss.backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.requires_grad}
+    return cfg, model, loss, aux, grads
+
+
+@pytest.mark.parametrize("name", ["tiny", "trunc", "mid"])
+def test_train_step_parity(name, golden_dir):
+    spec = GOLDEN_CONFIGS[name]
+    gold = load_file(os.path.join(golden_dir, f"{name}.safetensors"))
+    enc, dec = spec["enc"], spec["dec"]
+    params = zo.make_params(enc, dec, spec["seed"], surrogate=True)
+    imgs, ids, tgts, img_id, pad_id = zo.synth_batch(enc, dec, **spec["batch"])
+    # (b) live fp32 oracle on the same inputs (images rounded to bf16 like the device path)
+    imgs_r = [i.to(torch.bfloat16).float() for i in imgs]
+    ref = zo.train_step(params, enc, dec, imgs_r, ids, tgts, img_id=img_id, pad_id=pad_id,
+                        max_seq_len=spec["max_seq_len"], encoder_ft_layers_after=spec["ft_after"])
+    cfg, model, loss, aux, grads = run_hip(spec, params, imgs, ids, tgts, img_id, pad_id)
+
+    report = {}
+    # ---- loss / counts
+    assert int(aux["num_tokens"]) == int(ref.num_tokens) == int(gold["fp32.num_tokens"])
+    assert torch.equal(aux["target"], ref.target) and torch.equal(aux["target"], gold["fp32.target"])
+    report["loss"] = abs(loss.item() - ref.loss.item())
+    assert report["loss"] <= 1e-2 and report["loss"] <= 1e-2 * abs(ref.loss.item()), (loss.item(), ref.loss.item())
+    assert abs(loss.item() - gold["fp32.loss"].item()) <= 1.5e-2
+    # ---- assembled inputs (encoder + adapter + splice)
+    report["inputs_embeds"] = maxrel(aux["inputs_embeds"], ref.inputs_embeds)
+    floor = maxrel(gold["bf16.inputs_embeds"], gold["fp32.inputs_embeds"])
+    assert report["inputs_embeds"] <= max(2e-2, 2 * floor + 5e-3), (report, floor)
+    assert maxrel(shrink(aux["inputs_embeds"].detach().cpu()), gold["fp32.inputs_embeds"]) <= max(2e-2, 2 * floor + 5e-3)
+    # ---- full logits through the drop-in decoder call (engine:276-280)
+    with torch.no_grad():
+        logits = model.decoder(inputs_embeds=aux["inputs_embeds"].detach(), use_cache=False)["logits"]
+    report["logits"] = maxrel(logits, ref.logits)
+    floor_l = maxrel(gold["bf16.logits"], gold["fp32.logits"])
+    assert report["logits"] <= max(2e-2, 2 * floor_l + 5e-3), (report, floor_l)
+    assert maxrel(shrink(logits.cpu()), gold["fp32.logits"]) <= max(2e-2, 2 * floor_l + 5e-3)
+    # ---- gradient w.r.t. the assembled inputs (decoder backward)
+    report["d_inputs_embeds"] = normrel(aux["inputs_embeds"].grad, _d_inputs(ref, params, enc, dec, spec, imgs_r, ids, tgts, img_id, pad_id))
+    assert report["d_inputs_embeds"] <= 3e-2, report
+    # ---- trainable parameter gradients
+    worst = ("", 0.0)
+    assert set(grads) == set(ref.grads), set(grads) ^ set(ref.grads)
+    scale = max(v.float().norm().item() / v.numel() ** 0.5 for v in ref.grads.values())   # largest RMS
+    for n, g in grads.items():
+        assert g is not None, n
+        e = grad_err(g, ref.grads[n], scale * g.numel() ** 0.5)
+        if e > worst[1]:
+            worst = (n, e)
+        gk = "fp32.grad." + n
+        if gk in gold:
+            sg = shrink(g.detach().cpu())
+            assert grad_err(sg, gold[gk], scale * sg.numel() ** 0.5) <= 6e-2, n
+    report["worst_grad"] = worst
+    print(name, report)
+    assert worst[1] <= 3e-2, worst
+
+
+def _d_inputs(ref, params, enc, dec, spec, imgs, ids, tgts, img_id, pad_id):
+    """d loss / d inputs_embeds from the oracle (decoder + loss only)."""
+    x = ref.inputs_embeds.clone().requires_grad_(True)
+    logits = zo.llama_forward(params, x, dec)
+    loss_sum, ntok = zo.loss_tail(logits, ref.target, pad_id)
+    (loss_sum / ntok).backward()
+    return x.grad
+
+
+def test_drop_in_forward_list_contract():
+    """Zero._forward returns bs * [1 + P*T + 1, d] (adapter.py:116) and matches the oracle."""
+    spec = GOLDEN_CONFIGS["tiny"]
+    enc, dec = spec["enc"], spec["dec"]
+    params = zo.make_params(enc, dec, spec["seed"], surrogate=True)
+    imgs, *_ = zo.synth_batch(enc, dec, **spec["batch"])
+    from tests.helpers import build_model, make_cfg
+    cfg = make_cfg(enc, dec, DEV, spec["ft_after"], spec["max_seq_len"])
+    model = build_model(cfg, params)
+    xs = [torch.cat([imgs[0], imgs[2]]).to(DEV).to(torch.bfloat16), imgs[1].to(DEV).to(torch.bfloat16)]  # P = 2, 1
+    with torch.no_grad():
+        out = model._forward(xs)
+    ref = zo.zero_forward(params, [x.float().cpu() for x in xs], enc)
+    assert [tuple(o.shape) for o in out] == [tuple(r.shape) for r in ref] == [(2 + 2 * enc.tokens, dec.hidden), (2 + enc.tokens, dec.hidden)]
+    for o, r in zip(out, ref):
+        assert maxrel(o, r) <= 2e-2
+    # encoder contract: hidden_states tuple of Le+1 entries, last == last_hidden_state
+    with torch.no_grad():
+        eo = model.encoder(xs[0], output_hidden_states=True)
+    assert len(eo.hidden_states) == enc.layers + 1 and eo.hidden_states[-1] is eo.last_hidden_state
+    hs = zo.clip_vision_forward(params, xs[0].float().cpu(), enc)
+    for a, b in zip(eo.hidden_states, hs):
+        assert maxrel(a, b) <= 2e-2
+
+
+def test_trainer_step_updates_and_accumulates():
+    """Two micro-batches with gradient accumulation == the oracle's clip + AdamW on the summed
+    gradients; slots are written by the wgrad kernels (no autograd .grad)."""
+    spec = GOLDEN_CONFIGS["tiny"]
+    enc, dec = spec["enc"], spec["dec"]
+    params = zo.make_params(enc, dec, spec["seed"], surrogate=True)
+    from tests.helpers import build_model, make_cfg
+    from zero_amd.configs.zero.train_llama import func_optim_filter
+    from zero_amd.methods.engine_ar_instruction_llama import forward_from_ids
+    from zero_amd.train import Trainer
+    cfg = make_cfg(enc, dec, DEV, spec["ft_after"], spec["max_seq_len"])
+    cfg.gradient_accumulation_steps = 2
+    cfg.lr = 1e-3
+    cfg.grad_clip = 1.0
+    model = build_model(cfg, params)
+    groups = func_optim_filter(cfg, model)
+    tr = Trainer(cfg, model, forward_from_ids, groups, total_steps=100, warmup_steps=0)
+    try:
+        batches = [zo.synth_batch(enc, dec, **{**spec["batch"], "seed": s}) for s in (11, 12)]
+        ref_grads = None
+        for imgs, ids, tgts, img_id, pad_id in batches:
+            imgs_r = [i.to(torch.bfloat16).float() for i in imgs]
+            r = zo.train_step(params, enc, dec, imgs_r, ids, tgts, img_id=img_id, pad_id=pad_id,
+                              max_seq_len=spec["max_seq_len"], encoder_ft_layers_after=spec["ft_after"])
+            g = {k: v / 2 for k, v in r.grads.items()}
+            ref_grads = g if ref_grads is None else {k: ref_grads[k] + g[k] for k in g}
+            tr.micro_step([i.to(DEV).to(torch.bfloat16) for i in imgs], ids, tgts, img_id, pad_id)
+        # gradients as accumulated in the flat buffer
+        scale = max(v.float().norm().item() / v.numel() ** 0.5 for v in ref_grads.values())
+        worst = 0.0
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                assert p.grad is None
+                worst = max(worst, grad_err(p._zk_grad.view(p.shape), ref_grads[n], scale * p.numel() ** 0.5))
+        assert worst <= 3e-2, worst
+        # parameters after clip + AdamW (lr * cosine factor at step 1).  At step 1 Adam's update is
+        # lr * sign(g), so the optimizer is checked on the SAME gradients (those in the flat buffer):
+        # the gradient parity is the assertion above, this one is about the optimizer kernel.
+        dev_grads = {n: p._zk_grad.view(p.shape).float().cpu() for n, p in model.named_parameters() if p.requires_grad}
+        pref = {k: params[k].clone() for k in dev_grads}
+        total = zo.clip_and_adamw(pref, dev_grads, {}, lr=1e-3 * tr.lr_factor(1), step=1, max_norm=1.0)
+        assert abs(tr.grad_norm().item() - total.item()) <= 1e-3 * total.item()
+        moved, bad = 0, []
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                got = p.detach().float().cpu()
+                moved += (got - params[n]).abs().max().item() > 0
+                # bf16 parameter storage: one rounding of the updated value
+                tol = 2 ** -8 * pref[n].abs().max().item() + 1e-6
+                if (got - pref[n]).abs().max().item() > tol:
+                    bad.append(n)
+        assert moved > 6 and not bad, bad
+    finally:
+        tr.reducer.close()

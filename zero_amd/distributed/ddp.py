@@ -1,0 +1,168 @@
+"""Data-parallel gradient exchange for the trainable set (replaces torch DDP at
+ref:train.py:367 and ``no_sync`` at ref:train.py:562-564).
+
+Design (MI355X / RCCL over xGMI):
+  * only the TRAINABLE parameters (~113 M for the 3B config) are exchanged — the reference
+    registers every parameter with DDP before ``func_optim_filter`` runs and so all-reduces
+    the frozen 2.5 B surrogate as well; the result is identical;
+  * parameters and gradients live in two flat bf16 buffers laid out in gradient-ready order
+    (reverse registration order); packed q|k|v groups stay adjacent.  The wgrad kernels write
+    straight into the gradient slots (functional.GradSink), so there is no bucket copy;
+  * buckets are contiguous slices (~25 MB, DDP's default, about one encoder layer each);
+    a bucket's all-reduce (SUM; the 1/world average is folded into the optimizer kernel) is
+    launched asynchronously the moment its last slot has been written, overlapping the
+    remaining backward;
+  * gradient accumulation: ``no_sync()`` suppresses the launches; slots accumulate in place.
+"""
+from __future__ import annotations
+
+from contextlib import contextmanager
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from ..functional import GradSink
+
+
+def _pack_groups(params: List[nn.Parameter]) -> List[List[nn.Parameter]]:
+    """Keep tensors that are currently back-to-back in one storage (pack_params) together."""
+    by_storage: Dict[int, List[nn.Parameter]] = {}
+    for p in params:
+        by_storage.setdefault(p.untyped_storage().data_ptr(), []).append(p)
+    group_of: Dict[int, List[nn.Parameter]] = {}
+    for ps in by_storage.values():
+        ps = sorted(ps, key=lambda t: t.storage_offset())
+        run = [ps[0]]
+        for a, b in zip(ps, ps[1:]):
+            if b.storage_offset() == a.storage_offset() + a.numel():
+                run.append(b)
+            else:
+                for t in run:
+                    group_of[id(t)] = run
+                run = [b]
+        for t in run:
+            group_of[id(t)] = run
+    out, seen = [], set()
+    for p in params:
+        if id(p) in seen:
+            continue
+        g = group_of[id(p)]
+        out.append(g)
+        seen.update(id(t) for t in g)
+    return out
+
+
+class FlatGradReducer:
+    def __init__(self, model: nn.Module, bucket_bytes: int = 25 * 1024 * 1024, process_group=None):
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        if not named:
+            raise ValueError("no trainable parameters: call func_optim_filter before building the reducer")
+        self.names = {id(p): n for n, p in named}
+        ordered = [p for _, p in reversed(named)]                 # gradient-ready order
+        groups = _pack_groups(ordered)
+        self.params: List[nn.Parameter] = [p for g in groups for p in g]
+        dev = self.params[0].device
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 7) // 8 * 8                     # 16-byte aligned slots
+        self.numel = total
+        self.flat_param = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+        self.offset: Dict[int, int] = {}
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                n = p.numel()
+                self.flat_param[o:o + n].copy_(p.reshape(-1))
+                p.data = self.flat_param[o:o + n].view(p.shape)
+                p._zk_grad = self.flat_grad[o:o + n]
+                p._zk_dirty = False
+                self.offset[id(p)] = o
+        # contiguous buckets
+        self.buckets: List[dict] = []
+        cur = dict(start=0, end=0, params=[])
+        for p, o in zip(self.params, offs):
+            end = o + (p.numel() + 7) // 8 * 8
+            cur["params"].append(p)
+            cur["end"] = end
+            if (cur["end"] - cur["start"]) * 2 >= bucket_bytes:
+                self.buckets.append(cur)
+                cur = dict(start=end, end=end, params=[])
+        if cur["params"]:
+            self.buckets.append(cur)
+        self.bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b["params"]}
+        self._pending = [0] * len(self.buckets)
+        self._handles: List = []
+        self._sync = True
+        self._launched = [False] * len(self.buckets)
+        GradSink.listeners.append(self._on_grad)
+        self.begin_step()
+
+    # ---- step protocol ---------------------------------------------------------------
+    def begin_step(self):
+        """zero_grad(set_to_none=True) analogue: slots are overwritten by the first write."""
+        for p in self.params:
+            p._zk_dirty = False
+        self._begin_backward()
+
+    def _begin_backward(self):
+        self._pending = [len(b["params"]) for b in self.buckets]
+        self._seen = set()
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+
+    @contextmanager
+    def no_sync(self):
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+
+    def _on_grad(self, p):
+        i = self.bucket_of.get(id(p))
+        if i is None or id(p) in self._seen:
+            return
+        self._seen.add(id(p))
+        self._pending[i] -= 1
+        if self._pending[i] == 0 and self._sync:
+            self._launch(i)
+
+    def _launch(self, i):
+        if self._launched[i] or self.world == 1:
+            self._launched[i] = True
+            return
+        b = self.buckets[i]
+        self._handles.append(dist.all_reduce(self.flat_grad[b["start"]:b["end"]], op=dist.ReduceOp.SUM,
+                                             group=self.pg, async_op=True))
+        self._launched[i] = True
+
+    def finish_backward(self):
+        """After loss.backward(): zero the slots nothing wrote to, flush the remaining buckets,
+        wait for the exchanges (stream-ordered), and get ready for the next backward."""
+        for p in self.params:
+            if not p._zk_dirty:
+                p._zk_grad.zero_()
+                p._zk_dirty = True
+        if self._sync:
+            for i in range(len(self.buckets)):
+                if not self._launched[i]:
+                    self._launch(i)
+            for h in self._handles:
+                h.wait()
+        self._begin_backward()
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world                                   # DDP averages
+
+    def close(self):
+        if self._on_grad in GradSink.listeners:
+            GradSink.listeners.remove(self._on_grad)
+        for p in self.params:
+            if hasattr(p, "_zk_grad"):
+                del p._zk_grad

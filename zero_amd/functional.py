@@ -1,0 +1,516 @@
+"""Autograd nodes of the hot path.  One node per LAYER (not per op): forward and backward
+are explicit sequences of C-ABI kernel launches, activations are saved by hand, frozen
+weights get no wgrad and frozen layers save nothing.
+
+Parameter gradients: if a parameter carries a pre-assigned slot (``p._zk_grad``, a bf16 view
+into the trainer's flat gradient buffer, see distributed/ddp.py) the wgrad kernels write
+(or accumulate) straight into it and the node returns None for that input; otherwise the
+gradient tensor is returned to autograd as usual (plain drop-in behaviour).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+# ------------------------------------------------------------------------------------------
+# gradient sinks
+# ------------------------------------------------------------------------------------------
+class GradSink:
+    """Routes a parameter gradient either into its flat-buffer slot or back to autograd."""
+
+    listeners = []          # callables(param) fired when a slot has received its gradient
+
+    @staticmethod
+    def slot(p: torch.Tensor) -> Optional[torch.Tensor]:
+        return getattr(p, "_zk_grad", None)
+
+    @staticmethod
+    def is_dirty(p) -> bool:
+        return getattr(p, "_zk_dirty", False)
+
+    @staticmethod
+    def done(p):
+        p._zk_dirty = True
+        for fn in GradSink.listeners:
+            fn(p)
+
+
+def _wgrad(dy2d, x2d, w: torch.Tensor, need: bool):
+    """dW[out,in] = dY^T X, into the slot when there is one.  Returns what autograd should get."""
+    if not need:
+        return None
+    slot = GradSink.slot(w)
+    if slot is not None:
+        ops.gemm(dy2d, x2d, trans_a=True, trans_b=True, out=slot.view(w.shape), accumulate=GradSink.is_dirty(w))
+        GradSink.done(w)
+        return None
+    return ops.gemm(dy2d, x2d, trans_a=True, trans_b=True)
+
+
+def _vec_grad(acc_f32: torch.Tensor, p: torch.Tensor, need: bool):
+    """fp32 accumulated vector gradient (bias / norm affine) -> bf16 slot or autograd."""
+    if not need:
+        return None
+    slot = GradSink.slot(p)
+    if slot is not None:
+        ops.f32_to_bf16_(acc_f32, slot, accumulate=GradSink.is_dirty(p))
+        GradSink.done(p)
+        return None
+    out = torch.empty(p.shape, dtype=BF16, device=p.device)
+    ops.f32_to_bf16_(acc_f32, out)
+    return out
+
+
+def _bias_grad(dy2d, b: torch.Tensor, need: bool):
+    if not need:
+        return None
+    acc = torch.zeros(b.numel(), dtype=torch.float32, device=dy2d.device)
+    ops.colsum_(dy2d, acc)
+    return _vec_grad(acc, b, True)
+
+
+def adjacent(*ts: torch.Tensor) -> bool:
+    """True when the tensors are back-to-back slices of one storage (packed weights)."""
+    for a, b in zip(ts, ts[1:]):
+        if not (a.is_contiguous() and b.is_contiguous()):
+            return False
+        if a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr():
+            return False
+        if b.storage_offset() != a.storage_offset() + a.numel():
+            return False
+    return True
+
+
+def packed_rows(*ts: torch.Tensor) -> Optional[torch.Tensor]:
+    """[sum(out_i), in] view over adjacent [out_i, in] weights, or None."""
+    if not adjacent(*ts):
+        return None
+    rows = sum(t.shape[0] for t in ts)
+    return ts[0].as_strided((rows, ts[0].shape[1]), (ts[0].shape[1], 1))
+
+
+def packed_vec(*ts: torch.Tensor) -> Optional[torch.Tensor]:
+    if not adjacent(*ts):
+        return None
+    return ts[0].as_strided((sum(t.numel() for t in ts),), (1,))
+
+
+# ------------------------------------------------------------------------------------------
+# single ops as autograd nodes (drop-in module building blocks)
+# ------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b); epilogue in {NONE, QUICK_GELU, GELU_ERF}."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, epilogue):
+        x2 = x.reshape(-1, x.shape[-1])
+        need = any(ctx.needs_input_grad)
+        pre = None
+        if epilogue != ops.EPI_NONE and need:
+            pre = torch.empty((x2.shape[0], w.shape[0]), dtype=BF16, device=x.device)
+        y = ops.gemm(x2, w, bias=b, epilogue=epilogue, aux_out=pre)
+        ctx.epilogue = epilogue
+        ctx.save_for_backward(x2, w, b, pre)
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, b, pre = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        if ctx.epilogue != ops.EPI_NONE:
+            dy2 = ops.act_bwd(dy2, pre, ctx.epilogue)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dy2, w, trans_b=True).view(*dy.shape[:-1], w.shape[1])
+        dw = _wgrad(dy2, x2, w, ctx.needs_input_grad[1])
+        db = _bias_grad(dy2, b, b is not None and ctx.needs_input_grad[2])
+        return dx, dw, db, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        need = any(ctx.needs_input_grad)
+        y, mean, rstd = ops.layernorm_fwd(x2, gamma, beta, eps, save_stats=need)
+        ctx.save_for_backward(x2, gamma, beta, mean, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, beta, mean, rstd = ctx.saved_tensors
+        dy2 = dy.reshape(x2.shape)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        D = x2.shape[1]
+        dg = torch.zeros(D, dtype=torch.float32, device=x2.device) if need_p else None
+        db = torch.zeros(D, dtype=torch.float32, device=x2.device) if need_p else None
+        dx = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dgamma=dg, dbeta=db, need_dx=ctx.needs_input_grad[0])
+        return (dx.view(dy.shape) if dx is not None else None, _vec_grad(dg, gamma, ctx.needs_input_grad[1]),
+                _vec_grad(db, beta, ctx.needs_input_grad[2]), None)
+
+
+class RMSNormFn(torch.autograd.Function):
+    """Weight is treated as frozen (the surrogate decoder is frozen on this path)."""
+
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        y, rstd = ops.rmsnorm_fwd(x2, w, eps, save_stats=ctx.needs_input_grad[0])
+        ctx.save_for_backward(x2, w, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, rstd = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("RMSNorm weight gradient: the decoder is frozen on this path")
+        dy2 = dy.reshape(x2.shape)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        return ops.rmsnorm_bwd(dy2, x2, w, rstd).view(dy.shape), None, None
+
+
+# ------------------------------------------------------------------------------------------
+# CLIP encoder layer (tf:clip:362-383) as one node
+# ------------------------------------------------------------------------------------------
+class EncoderLayerFn(torch.autograd.Function):
+    """inputs: x [B,T,D], then the 16 parameter tensors in state-dict order:
+    ln1.w ln1.b  q.w q.b k.w k.b v.w v.b o.w o.b  ln2.w ln2.b  fc1.w fc1.b fc2.w fc2.b ; heads, eps"""
+
+    @staticmethod
+    def forward(ctx, x, l1w, l1b, qw, qb, kw, kb, vw, vb, ow, ob, l2w, l2b, f1w, f1b, f2w, f2b, heads, eps):
+        B, T, D = x.shape
+        M = B * T
+        hd = D // heads
+        need = any(ctx.needs_input_grad)
+        x2 = x.reshape(M, D)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        h1, mean1, rstd1 = ops.layernorm_fwd(x2, l1w, l1b, eps, save_stats=need)
+        qkv = torch.empty((M, 3 * D), dtype=BF16, device=x.device)
+        wqkv, bqkv = packed_rows(qw, kw, vw), packed_vec(qb, kb, vb)
+        if wqkv is not None and bqkv is not None:
+            ops.gemm(h1, wqkv, bias=bqkv, out=qkv)
+        else:
+            for i, (w_, b_) in enumerate(((qw, qb), (kw, kb), (vw, vb))):
+                ops.gemm(h1, w_, bias=b_, out=qkv[:, i * D:(i + 1) * D])
+        ao, lse = ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, T, heads, heads, hd, hd ** -0.5,
+                               False, need_lse=need)
+        xa = ops.gemm(ao, ow, bias=ob, residual=x2)
+        h2, mean2, rstd2 = ops.layernorm_fwd(xa, l2w, l2b, eps, save_stats=need)
+        pre = torch.empty((M, f1w.shape[0]), dtype=BF16, device=x.device) if need else None
+        act = ops.gemm(h2, f1w, bias=f1b, epilogue=ops.EPI_QUICK_GELU, aux_out=pre)
+        y = ops.gemm(act, f2w, bias=f2b, residual=xa)
+        if need:
+            ctx.save_for_backward(x2, mean1, rstd1, h1, qkv, ao, lse, xa, mean2, rstd2, h2, pre, act,
+                                  l1w, l1b, qw, qb, kw, kb, vw, vb, ow, ob, l2w, l2b, f1w, f1b, f2w, f2b)
+            ctx.dims = (B, T, D, heads, hd)
+        return y.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2, mean1, rstd1, h1, qkv, ao, lse, xa, mean2, rstd2, h2, pre, act,
+         l1w, l1b, qw, qb, kw, kb, vw, vb, ow, ob, l2w, l2b, f1w, f1b, f2w, f2b) = ctx.saved_tensors
+        B, T, D, heads, hd = ctx.dims
+        M = B * T
+        nig = ctx.needs_input_grad
+        dev = dy.device
+        dy2 = dy.reshape(M, D)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+        # ---- MLP block:  y = xa + fc2(quick_gelu(fc1(LN2(xa))))
+        d_pre = ops.gemm(dy2, f2w, trans_b=True, epilogue=ops.EPI_MUL_DQUICK_GELU, aux_in=pre)
+        g_f2w = _wgrad(dy2, act, f2w, nig[15])
+        g_f2b = _bias_grad(dy2, f2b, nig[16])
+        g_f1w = _wgrad(d_pre, h2, f1w, nig[13])
+        g_f1b = _bias_grad(d_pre, f1b, nig[14])
+        d_h2 = ops.gemm(d_pre, f1w, trans_b=True)
+        need_ln2 = nig[11] or nig[12]
+        dg2, db2 = (f32(D), f32(D)) if need_ln2 else (None, None)
+        dxa = ops.layernorm_bwd(d_h2, xa, l2w, mean2, rstd2, dres=dy2, dgamma=dg2, dbeta=db2)
+        g_l2w, g_l2b = _vec_grad(dg2, l2w, nig[11]), _vec_grad(db2, l2b, nig[12])
+        # ---- attention block:  xa = x + out(attn(qkv(LN1(x))))
+        d_ao = ops.gemm(dxa, ow, trans_b=True)
+        g_ow = _wgrad(dxa, ao, ow, nig[9])
+        g_ob = _bias_grad(dxa, ob, nig[10])
+        d_qkv = torch.empty_like(qkv)
+        ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, d_ao, lse, d_qkv[:, :D], d_qkv[:, D:2 * D],
+                     d_qkv[:, 2 * D:], B, T, heads, heads, hd, hd ** -0.5, False)
+        wqkv = packed_rows(qw, kw, vw)
+        slots_w = [GradSink.slot(p) for p in (qw, kw, vw)]
+        slots_b = [GradSink.slot(p) for p in (qb, kb, vb)]
+        g_qw = g_kw = g_vw = g_qb = g_kb = g_vb = None
+        packed_slots = (all(s is not None for s in slots_w) and adjacent(*slots_w) and nig[3] and nig[5] and nig[7]
+                        and len({GradSink.is_dirty(p) for p in (qw, kw, vw)}) == 1)
+        if packed_slots:
+            ops.gemm(d_qkv, h1, trans_a=True, trans_b=True, out=packed_rows(*[s.view(D, D) for s in slots_w]),
+                     accumulate=GradSink.is_dirty(qw))
+            for p in (qw, kw, vw):
+                GradSink.done(p)
+        else:
+            g_qw = _wgrad(d_qkv[:, :D], h1, qw, nig[3])
+            g_kw = _wgrad(d_qkv[:, D:2 * D], h1, kw, nig[5])
+            g_vw = _wgrad(d_qkv[:, 2 * D:], h1, vw, nig[7])
+        if nig[4] or nig[6] or nig[8]:
+            acc = f32(3 * D)
+            ops.colsum_(d_qkv, acc)
+            g_qb = _vec_grad(acc[:D].contiguous(), qb, nig[4])
+            g_kb = _vec_grad(acc[D:2 * D].contiguous(), kb, nig[6])
+            g_vb = _vec_grad(acc[2 * D:].contiguous(), vb, nig[8])
+        need_dx = nig[0]
+        dx = None
+        g_l1w = g_l1b = None
+        if need_dx or nig[1] or nig[2]:
+            if wqkv is not None:
+                d_h1 = ops.gemm(d_qkv, wqkv, trans_b=True)
+            else:
+                d_h1 = ops.gemm(d_qkv[:, :D], qw, trans_b=True)
+                ops.gemm(d_qkv[:, D:2 * D], kw, trans_b=True, out=d_h1, accumulate=True)
+                ops.gemm(d_qkv[:, 2 * D:], vw, trans_b=True, out=d_h1, accumulate=True)
+            dg1, db1 = (f32(D), f32(D)) if (nig[1] or nig[2]) else (None, None)
+            dx = ops.layernorm_bwd(d_h1, x2, l1w, mean1, rstd1, dres=dxa, dgamma=dg1, dbeta=db1, need_dx=need_dx)
+            g_l1w, g_l1b = _vec_grad(dg1, l1w, nig[1]), _vec_grad(db1, l1b, nig[2])
+            if dx is not None:
+                dx = dx.view(B, T, D)
+        return (dx, g_l1w, g_l1b, g_qw, g_qb, g_kw, g_kb, g_vw, g_vb, g_ow, g_ob, g_l2w, g_l2b,
+                g_f1w, g_f1b, g_f2w, g_f2b, None, None)
+
+
+# ------------------------------------------------------------------------------------------
+# Llama decoder layer (tf:llama:295-324), frozen weights: dgrad only
+# ------------------------------------------------------------------------------------------
+class DecoderLayerFn(torch.autograd.Function):
+    """inputs: x [B,S,d]; ln1.w; q.w k.w v.w o.w; ln2.w; gate.w up.w down.w; cos, sin; cfg tuple."""
+
+    @staticmethod
+    def forward(ctx, x, l1w, qw, kw, vw, ow, l2w, gw, uw, dw, cos_t, sin_t, dims):
+        nh, nkv, hd, eps = dims
+        B, S, d = x.shape
+        M = B * S
+        need = ctx.needs_input_grad[0]
+        if any(ctx.needs_input_grad[1:10]):
+            raise NotImplementedError("decoder weights are frozen on the encoder-training path (SURVEY.md §8f row 2)")
+        x2 = x.reshape(M, d)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        h1, rstd1 = ops.rmsnorm_fwd(x2, l1w, eps, save_stats=need)
+        W = (nh + 2 * nkv) * hd
+        qkv = torch.empty((M, W), dtype=BF16, device=x.device)
+        wqkv = packed_rows(qw, kw, vw)
+        if wqkv is not None:
+            ops.gemm(h1, wqkv, out=qkv)
+        else:
+            ops.gemm(h1, qw, out=qkv[:, :nh * hd])
+            ops.gemm(h1, kw, out=qkv[:, nh * hd:(nh + nkv) * hd])
+            ops.gemm(h1, vw, out=qkv[:, (nh + nkv) * hd:])
+        ops.rope_(qkv, cos_t, sin_t, S, nh + nkv, hd)
+        q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
+        ao, lse = ops.attn_fwd(q, k, v, B, S, nh, nkv, hd, hd ** -0.5, S > 1, need_lse=need)
+        xa = ops.gemm(ao, ow, residual=x2)
+        h2, rstd2 = ops.rmsnorm_fwd(xa, l2w, eps, save_stats=need)
+        F = gw.shape[0]
+        wgu = packed_rows(gw, uw)
+        if wgu is not None:
+            gu = ops.gemm(h2, wgu)
+        else:
+            gu = torch.empty((M, 2 * F), dtype=BF16, device=x.device)
+            ops.gemm(h2, gw, out=gu[:, :F])
+            ops.gemm(h2, uw, out=gu[:, F:])
+        hm = ops.swiglu_fwd(gu, F)
+        y = ops.gemm(hm, dw, residual=xa)
+        if need:
+            ctx.save_for_backward(x2, rstd1, qkv, ao, lse, xa, rstd2, gu, l1w, qw, kw, vw, ow, l2w, gw, uw, dw,
+                                  cos_t, sin_t)
+            ctx.dims = (B, S, d, nh, nkv, hd, F)
+        return y.view(B, S, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2, rstd1, qkv, ao, lse, xa, rstd2, gu, l1w, qw, kw, vw, ow, l2w, gw, uw, dw, cos_t, sin_t) = ctx.saved_tensors
+        B, S, d, nh, nkv, hd, F = ctx.dims
+        M = B * S
+        dy2 = dy.reshape(M, d)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        d_hm = ops.gemm(dy2, dw, trans_b=True)
+        d_gu = ops.swiglu_bwd(d_hm, gu, F)
+        wgu = packed_rows(gw, uw)
+        if wgu is not None:
+            d_h2 = ops.gemm(d_gu, wgu, trans_b=True)
+        else:
+            d_h2 = ops.gemm(d_gu[:, :F], gw, trans_b=True)
+            ops.gemm(d_gu[:, F:], uw, trans_b=True, out=d_h2, accumulate=True)
+        dxa = ops.rmsnorm_bwd(d_h2, xa, l2w, rstd2, dres=dy2)
+        d_ao = ops.gemm(dxa, ow, trans_b=True)
+        d_qkv = torch.empty_like(qkv)
+        q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
+        ops.attn_bwd(q, k, v, ao, d_ao, lse, d_qkv[:, :nh * hd], d_qkv[:, nh * hd:(nh + nkv) * hd],
+                     d_qkv[:, (nh + nkv) * hd:], B, S, nh, nkv, hd, hd ** -0.5, S > 1)
+        ops.rope_(d_qkv, cos_t, sin_t, S, nh + nkv, hd, inverse=True)
+        wqkv = packed_rows(qw, kw, vw)
+        if wqkv is not None:
+            d_h1 = ops.gemm(d_qkv, wqkv, trans_b=True)
+        else:
+            d_h1 = ops.gemm(d_qkv[:, :nh * hd], qw, trans_b=True)
+            ops.gemm(d_qkv[:, nh * hd:(nh + nkv) * hd], kw, trans_b=True, out=d_h1, accumulate=True)
+            ops.gemm(d_qkv[:, (nh + nkv) * hd:], vw, trans_b=True, out=d_h1, accumulate=True)
+        dx = ops.rmsnorm_bwd(d_h1, x2, l1w, rstd1, dres=dxa)
+        return (dx.view(B, S, d),) + (None,) * 12
+
+
+# ------------------------------------------------------------------------------------------
+# adapter MLP (ref:models/adapter.py:34-38,95): Linear -> exact GELU -> Linear
+# ------------------------------------------------------------------------------------------
+class AdapterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w0, b0, w2, b2):
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        need = any(ctx.needs_input_grad)
+        pre = torch.empty((x2.shape[0], w0.shape[0]), dtype=BF16, device=x.device) if need else None
+        act = ops.gemm(x2, w0, bias=b0, epilogue=ops.EPI_GELU_ERF, aux_out=pre)
+        y = ops.gemm(act, w2, bias=b2)
+        if need:
+            ctx.save_for_backward(x2, pre, act, w0, b0, w2, b2)
+        return y.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, pre, act, w0, b0, w2, b2 = ctx.saved_tensors
+        nig = ctx.needs_input_grad
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        d_pre = ops.gemm(dy2, w2, trans_b=True, epilogue=ops.EPI_MUL_DGELU_ERF, aux_in=pre)
+        g_w2 = _wgrad(dy2, act, w2, nig[3])
+        g_b2 = _bias_grad(dy2, b2, nig[4])
+        g_w0 = _wgrad(d_pre, x2, w0, nig[1])
+        g_b0 = _bias_grad(d_pre, b0, nig[2])
+        dx = ops.gemm(d_pre, w0, trans_b=True) if nig[0] else None
+        if dx is not None:
+            dx = dx.view(*dy.shape[:-1], w0.shape[1])
+        return dx, g_w0, g_b0, g_w2, g_b2
+
+
+# ------------------------------------------------------------------------------------------
+# input assembly (ref:engine:186-236) and its backward
+# ------------------------------------------------------------------------------------------
+class SpliceFn(torch.autograd.Function):
+    """inputs_embeds[r] = wte[code] | 0 | imgtab[-2-code]  for the flat [B*S] row codes.
+
+    imgtab = [adapter rows ; soi ; eoi].  Backward gathers d_inputs through ``inv_codes``
+    (row of d_inputs that consumed each adapter row, -1 if truncated away) and sums the
+    soi / eoi rows over the batch; wte is frozen."""
+
+    @staticmethod
+    def forward(ctx, img_rows, soi, eoi, wte, codes, inv_codes, soi_pos, eoi_pos, B, S):
+        d = wte.shape[1]
+        n = img_rows.shape[0]
+        imgtab = torch.empty((n + 2, d), dtype=BF16, device=wte.device)
+        imgtab[:n].copy_(img_rows)
+        imgtab[n].copy_(soi.reshape(-1))
+        imgtab[n + 1].copy_(eoi.reshape(-1))
+        out = ops.gather_rows(wte, imgtab, codes, d)
+        ctx.save_for_backward(inv_codes, soi_pos, eoi_pos, soi, eoi)
+        ctx.d = d
+        return out.view(B, S, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        inv_codes, soi_pos, eoi_pos, soi, eoi = ctx.saved_tensors
+        d = ctx.d
+        dy2 = dy.reshape(-1, d)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        d_img = ops.gather_rows(dy2, None, inv_codes, d) if ctx.needs_input_grad[0] else None
+        outs = []
+        for pos, p, need in ((soi_pos, soi, ctx.needs_input_grad[1]), (eoi_pos, eoi, ctx.needs_input_grad[2])):
+            if not need:
+                outs.append(None)
+                continue
+            rows = ops.gather_rows(dy2, None, pos, d)
+            acc = torch.zeros(d, dtype=torch.float32, device=dy.device)
+            ops.colsum_(rows, acc)
+            outs.append(_vec_grad(acc, p, True))
+        return (d_img, outs[0], outs[1]) + (None,) * 7
+
+
+# ------------------------------------------------------------------------------------------
+# final norm + lm_head + shifted token-sum cross entropy (tf:llama:413,480; ref:engine:280-305)
+# ------------------------------------------------------------------------------------------
+class LMHeadLossFn(torch.autograd.Function):
+    """loss_sum over the rows listed in ``rows`` (flat positions whose shifted label is not
+    ignored) — rows with ignore_index contribute neither loss nor gradient, so the lm_head
+    product is only formed for the listed rows.  Returns the fp32 loss sum (0-dim)."""
+
+    @staticmethod
+    def forward(ctx, hidden, norm_w, lm_w, rows, labels, inv_rows, eps):
+        B, S, d = hidden.shape
+        x2 = hidden.reshape(B * S, d)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        need = ctx.needs_input_grad[0]
+        acc = torch.zeros(2, dtype=torch.float32, device=hidden.device)
+        n = rows.numel()
+        if n == 0:
+            ctx.empty = True
+            ctx.shape = hidden.shape
+            return acc[0]
+        xs = ops.gather_rows(x2, None, rows, d)
+        hn, rstd = ops.rmsnorm_fwd(xs, norm_w, eps, save_stats=need)
+        logits = ops.gemm(hn, lm_w)
+        ops.cross_entropy(logits, labels, acc, logits if need else None)
+        ctx.empty = False
+        ctx.shape = hidden.shape
+        if need:
+            ctx.save_for_backward(xs, rstd, logits, norm_w, lm_w, inv_rows)
+        return acc[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        B, S, d = ctx.shape
+        if ctx.empty:
+            return (torch.zeros(ctx.shape, dtype=BF16, device=g.device),) + (None,) * 6
+        xs, rstd, dlogits, norm_w, lm_w, inv = ctx.saved_tensors
+        g32 = g.reshape(1).to(torch.float32).contiguous()
+        d_hn = ops.gemm(dlogits, lm_w, trans_b=True, alpha_dev=g32)
+        d_xs = ops.rmsnorm_bwd(d_hn, xs, norm_w, rstd)
+        # scatter the listed rows back through the inverse map (-1 = no gradient: zero row)
+        dx = ops.gather_rows(d_xs, None, inv, d)
+        return (dx.view(B, S, d),) + (None,) * 6
+
+
+class CrossEntropySumFn(torch.autograd.Function):
+    """Token-sum cross entropy over FULL bf16 logits [rows, V] with int32 labels (-100 ignored):
+    the drop-in tail for a decoder that only exposes ``["logits"]`` (ref:engine:280-305)."""
+
+    @staticmethod
+    def forward(ctx, logits2d, labels):
+        acc = torch.zeros(2, dtype=torch.float32, device=logits2d.device)
+        need = ctx.needs_input_grad[0]
+        dl = torch.empty_like(logits2d) if need else None
+        ops.cross_entropy(logits2d, labels, acc, dl)
+        if need:
+            ctx.save_for_backward(dl)
+        return acc[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return (dl.float() * g).to(BF16), None

@@ -1,0 +1,95 @@
+"""The DDP training step of the reference (ref:train.py:367,381-387,523-583) on HIP kernels.
+
+``Trainer`` owns what train.py's loop owns: the bound forward, the gradient exchange
+(distributed/ddp.py), grad-norm clipping and AdamW (ONE fused kernel over the flat trainable
+buffer: clip coefficient from a device-side sum of squares, no host sync), the cosine
+schedule with linear warm-up (train.py:410-414,495-521) and gradient accumulation with
+``no_sync``.  bf16 parameters without an fp32 master copy, like the reference
+(``model.to(bf16)`` then AdamW on those tensors, train.py:209,382); the Adam moments are kept in
+fp32."""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .distributed.ddp import FlatGradReducer
+
+
+class Trainer:
+    def __init__(self, cfg, model: nn.Module, forward_fn: Callable, optim_groups: List[dict], *,
+                 total_steps: int = 1000, warmup_steps: int = 0, process_group=None, bucket_bytes=25 << 20):
+        self.cfg, self.model = cfg, model
+        self.forward = forward_fn.__get__(model, model.__class__)          # train.py:213-214
+        self.reducer = FlatGradReducer(model, bucket_bytes=bucket_bytes, process_group=process_group)
+        r = self.reducer
+        dev = r.flat_param.device
+        self.m = torch.zeros(r.numel, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(r.numel, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        # (lr, wd) per parameter from the reference-style groups, merged into contiguous segments
+        hp = {}
+        for g in optim_groups:
+            for p in g["params"]:
+                hp[id(p)] = (float(g["lr"]), float(g.get("weight_decay", 0.0)))
+        segs = []
+        for p in r.params:
+            o = r.offset[id(p)]
+            e = o + (p.numel() + 7) // 8 * 8
+            h = hp.get(id(p), (float(cfg.lr), 0.0))
+            if segs and segs[-1][2] == h and segs[-1][1] == o:
+                segs[-1][1] = e
+            else:
+                segs.append([o, e, h])
+        self.segments = segs
+        self.total_steps, self.warmup_steps = total_steps, warmup_steps
+        self.global_step = 0
+        self.accum = max(1, int(cfg.gradient_accumulation_steps))
+        self._micro = 0
+
+    def lr_factor(self, step: int) -> float:
+        """Linear warm-up then cosine to cfg.min_lr (CosineAnnealingLR, train.py:410-414,495-521)."""
+        if self.warmup_steps > 0 and step <= self.warmup_steps:
+            return step / self.warmup_steps
+        t = min(step, self.total_steps)
+        return 0.5 * (1 + math.cos(math.pi * t / max(1, self.total_steps)))
+
+    def micro_step(self, *fwd_args, **fwd_kwargs) -> torch.Tensor:
+        """forward + backward of one micro-batch; the optimizer runs on the last one."""
+        r = self.reducer
+        last = (self._micro + 1) % self.accum == 0
+        if self._micro % self.accum == 0:
+            r.begin_step()
+        loss = self.forward(self.cfg, *fwd_args, **fwd_kwargs)             # train.py:524
+        scaled = loss / self.accum                                          # train.py:527
+        if last:
+            scaled.backward()                                               # train.py:567
+            r.finish_backward()
+            self.optimizer_step()
+        else:
+            with r.no_sync():                                               # train.py:562-564
+                scaled.backward()
+                r.finish_backward()
+        self._micro += 1
+        return loss.detach()
+
+    def optimizer_step(self):
+        r, cfg = self.reducer, self.cfg
+        self.global_step += 1
+        self.sumsq.zero_()
+        max_norm = float(cfg.grad_clip)
+        if max_norm > 0:
+            ops.sumsq_(r.flat_grad, self.sumsq, scale=r.grad_scale)         # clip_grad_norm_ (train.py:574-576)
+        f = self.lr_factor(self.global_step)
+        for o, e, (lr, wd) in self.segments:
+            min_lr = float(getattr(cfg, "min_lr", 0.0))
+            cur = min_lr + (lr - min_lr) * f if self.global_step > self.warmup_steps else lr * f
+            ops.adamw_step_(r.flat_param[o:e], r.flat_grad[o:e], self.m[o:e], self.v[o:e], lr=cur,
+                            beta1=cfg.adamw_beta1, beta2=cfg.adamw_beta2, eps=1e-8, weight_decay=wd,
+                            step=self.global_step, max_norm=max_norm, sumsq=self.sumsq, grad_scale=r.grad_scale)
+
+    def grad_norm(self) -> torch.Tensor:
+        return self.sumsq.sqrt()
