@@ -1,0 +1,271 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the encoder + adapter + surrogate-decoder TRAIN STEP
+(forward + backward + gradient all-reduce + grad-norm clip + AdamW) on synthetic 336 px
+images plus text tokens — BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1: plain python;
+    N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+Workloads (--workload):
+    c3 (default)  Llama-3.2-3B surrogate (18 layers) step, B = 8 per GPU, S = 768   [configs[2]]
+    c4            Llama-3.1-8B surrogate (19 layers) step, B = 8 per GPU, S = 768   [configs[3]]
+    c2            ViT encoder + adapter forward/backward only, B = 64               [configs[1]]
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 8; 64 for c2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def flops_per_image(enc_layers, ft_after, d, nh, nkv, f, Ld, V, S, T=577, D=1024, F=4096, H=16, n_valid=128,
+                    full_lm_head=True):
+    """SURVEY.md §8a counting rules: linear 2MKN; attention fwd 4 T^2 H hd (x1/2 causal);
+    trainable bwd 2x fwd; frozen bwd 1x (GEMM) / 2x (attention)."""
+    enc_layer = 2 * T * (4 * D * D + 2 * D * F) + 4 * T * T * D
+    patch = 2 * 576 * 588 * D
+    enc_fwd = enc_layers * enc_layer + patch
+    enc_bwd = (enc_layers - ft_after) * 2 * enc_layer
+    adapter = 2 * T * (D * d + d * d)
+    hd = 128
+    dec_gemm = 2 * S * (d * (nh + 2 * nkv) * hd + nh * hd * d + 3 * d * f)
+    dec_attn = 4 * S * S * nh * hd * 0.5
+    rows = S if full_lm_head else n_valid
+    lm = 2 * rows * d * V
+    total = enc_fwd + enc_bwd + 3 * adapter + Ld * (2 * dec_gemm + 3 * dec_attn) + 2 * lm
+    return total
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from oracle import zero_oracle as zo   # cpu_baseline leg + synthetic batch generator only
+    from zero_amd import ops
+    from zero_amd.build_decoder import load_hf_llama3
+    from zero_amd.build_encoder import load_clip
+    from zero_amd.configs.zero import train_llama as run_cfg
+    from zero_amd.methods.engine_ar_instruction_llama import forward_from_ids
+    from zero_amd.models.adapter import Zero
+    from zero_amd.train import Trainer
+
+    import copy
+    cfg = copy.deepcopy(run_cfg.config)
+    cfg.device = device
+    if args.workload == "c4":
+        cfg.llama_model_version, cfg.llama_model_scale = "3.1", "8"
+        from zero_amd.configs.config_base import LLAMA_SHAPES
+        cfg.translators_range = LLAMA_SHAPES[("3.1", "8")]["translators_range"]
+    B = args.batch or (64 if args.workload == "c2" else 8)
+    cfg.batch_size = B
+
+    # ---- model: identical seeded random init on every rank (DDP broadcasts rank 0's weights)
+    torch.manual_seed(1337)
+    quiet = open(os.devnull, "w")
+    stdout, sys.stdout = sys.stdout, quiet
+    try:
+        encoder, _, img_size = load_clip(cfg)
+        if args.workload == "c2":
+            from zero_amd.configs.config_base import LLAMA_SHAPES
+            num_embd, decoder = LLAMA_SHAPES[("3.2", "3")]["hidden_size"], None
+        else:
+            num_embd, decoder, _, _, _ = load_hf_llama3(cfg)
+    finally:
+        sys.stdout = stdout
+    cfg.num_embd = num_embd
+    model = Zero(cfg, encoder, decoder)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "norm" in n and n.endswith("weight"):
+                p.fill_(1.0)
+    groups = run_cfg.func_optim_filter(cfg, model)
+    model.train()
+
+    # ---- synthetic data: seeded per rank
+    g = torch.Generator(device="cpu").manual_seed(1337 + rank)
+    n_pre, n_post, n_resp = 21, 168, 128
+    T = (img_size // 14) ** 2 + 1
+    dcfg = zo.DecoderCfg(vocab=128256)
+    ecfg = zo.EncoderCfg()
+    imgs_cpu, ids, tgts, img_id, pad_id = zo.synth_batch(ecfg, dcfg, B, 1337 + rank, n_pre=n_pre, n_post=n_post,
+                                                         n_resp=n_resp)
+    imgs = [i.to(device).to(torch.bfloat16) for i in imgs_cpu]
+    S = n_pre + (T + 2) + n_post
+
+    if args.workload == "c2":
+        def c2_forward(self, cfg_, imgs_):
+            rows, _, _ = self._encode_rows(imgs_)
+            # a scalar objective that reaches every trainable tensor: mean of the adapter output
+            return _MeanFn.apply(rows)
+        trainer = Trainer(cfg, model, c2_forward, groups)
+        step = lambda: trainer.micro_step(imgs)
+    else:
+        trainer = Trainer(cfg, model, forward_from_ids, groups)
+        step = lambda: trainer.micro_step(imgs, ids, tgts, img_id, pad_id)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms_per_step = dt / args.steps * 1e3
+    images_per_s = B * world * args.steps / dt
+
+    # ---- per-kernel timing of the GEMM family, live, with HIP events on the launch stream
+    roofline = None
+    if rank == 0 and not args.no_kernel_timing:
+        records = []
+        real_gemm = ops.gemm
+
+        def timed_gemm(a, b, *, trans_a=False, trans_b=False, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = real_gemm(a, b, trans_a=trans_a, trans_b=trans_b, **kw)
+            e1.record()
+            M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+            N = b.shape[1] if trans_b else b.shape[0]
+            records.append(((trans_a, trans_b), 2.0 * M * N * K, e0, e1, (M, N, K)))
+            return out
+        ops.gemm = timed_gemm
+        try:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+        finally:
+            ops.gemm = real_gemm
+        fam = {}
+        for key, fl, e0, e1, shp in records:
+            d = fam.setdefault(key, dict(n=0, ms=0.0, flops=0.0))
+            d["n"] += 1; d["ms"] += e0.elapsed_time(e1); d["flops"] += fl
+        key = max(fam, key=lambda k: fam[k]["ms"])
+        d = fam[key]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "kernel": f"gemm_kernel<transA={int(key[0])},transB={int(key[1])}>",
+                    "launches_per_step": d["n"] // 2, "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 1),
+                    "avg_gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 1),
+                    "gemm_ms_per_step": round(sum(v["ms"] for v in fam.values()) / 2, 2),
+                    "families": {f"tA{int(k[0])}tB{int(k[1])}": {"n": v["n"] // 2, "ms": round(v["ms"] / 2, 2),
+                                                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                                 for k, v in fam.items()}}
+
+    # ---- CPU baseline: the oracle on the host cores, rank 0, N = 1 only, bounded sample
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "c2":
+        cores = os.cpu_count() or 1
+        cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+        torch.set_num_threads(cores)
+        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        if "decoder.lm_head.weight" in sd and model.decoder.config.tie_word_embeddings:
+            del sd["decoder.lm_head.weight"]
+        dc = model.decoder.config
+        odec = zo.DecoderCfg(hidden=dc.hidden_size, heads=dc.num_attention_heads, kv_heads=dc.num_key_value_heads,
+                             head_dim=dc.head_dim, intermediate=dc.intermediate_size, layers=dc.num_hidden_layers,
+                             vocab=dc.vocab_size, rope_factor=dc.rope_scaling["factor"], tie=dc.tie_word_embeddings)
+        t0 = time.perf_counter()
+        r = zo.train_step(sd, ecfg, odec, [imgs_cpu[0].to(torch.bfloat16).float()], ids[:1], tgts[:1], img_id=img_id,
+                          pad_id=pad_id, encoder_ft_layers_after=cfg.encoder_ft_layers_after)
+        cdt = time.perf_counter() - t0
+        cpu_baseline = {"value": round(1.0 / cdt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+                        "sample": f"1 image (S={S}) of the same workload: one fp32 forward+backward of the oracle "
+                                  f"(oracle/zero_oracle.py) in {cdt:.1f} s, optimizer excluded",
+                        "loss": round(float(r.loss), 4)}
+
+    if rank == 0:
+        dc = model.decoder.config if decoder is not None else None
+        if dc is not None:
+            Ld = len(model.decoder.model.layers)
+            fl_alg = flops_per_image(24, cfg.encoder_ft_layers_after, dc.hidden_size, dc.num_attention_heads,
+                                     dc.num_key_value_heads, dc.intermediate_size, Ld, dc.vocab_size, S)
+            fl_exec = flops_per_image(24, cfg.encoder_ft_layers_after, dc.hidden_size, dc.num_attention_heads,
+                                      dc.num_key_value_heads, dc.intermediate_size, Ld, dc.vocab_size, S,
+                                      n_valid=n_resp, full_lm_head=False)
+        else:
+            fl_alg = fl_exec = 0.680e12
+        per_gpu = images_per_s / world
+        out = {
+            "metric": "images/sec (node) for encoder+surrogate train step",
+            "value": round(images_per_s, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": {"c3": "Llama-3.2-3B surrogate (18 layers) encoder-training step, encoder "
+                                           "layers 16-23 + adapter trainable, surrogate frozen",
+                                    "c4": "Llama-3.1-8B surrogate (19 layers) encoder-training step",
+                                    "c2": "ViT-L/14-336 encoder + adapter forward/backward"}[args.workload],
+                       "per_gpu_batch": B, "global_batch": B * world, "seq_len": S, "image": "336x336",
+                       "parallelism": f"dp{world}", "grad_accum": 1, "weights": "seeded random init"},
+            "loss": round(float(loss), 4),
+            "tflop_per_image_algorithmic": round(fl_alg / 1e12, 3),
+            "tflop_per_image_executed": round(fl_exec / 1e12, 3),
+            "mfma_util_step": round(per_gpu * fl_exec / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+class _MeanFn(torch.autograd.Function):
+    """c2 objective: mean over all adapter outputs (bf16 rows) via the column-sum kernel."""
+
+    @staticmethod
+    def forward(ctx, rows):
+        from zero_amd import ops
+        acc = torch.zeros(rows.shape[1], dtype=torch.float32, device=rows.device)
+        ops.colsum_(rows, acc)
+        ctx.shape = rows.shape
+        return acc.sum() / rows.numel()
+
+    @staticmethod
+    def backward(ctx, g):
+        n = ctx.shape[0] * ctx.shape[1]
+        return (g / n).to(torch.bfloat16).expand(ctx.shape).contiguous()
+
+
+if __name__ == "__main__":
+    main()
