@@ -131,16 +131,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* dy, co
     }
   }
   if (dgamma) {
+    // block-level reduction through LDS (the 4 waves take turns), then ONE atomic per column per
+    // block: with every wave adding into the same [D] words the kernel ran at the contended
+    // atomic rate (0.69 ms per call at 4616 x 1024; profiles/r01_bench_c3_kernel_stats_v1.csv).
+    __shared__ float red[2][MAXV * 512];
+    const int wave = threadIdx.x >> 6;
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      int idx = lane + 64 * i;
-      if (idx < nv) {
+        for (int i = 0; i < MAXV; ++i) {
+          int idx = lane + 64 * i;
+          if (idx < nv) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          atomicAdd(dgamma + idx * 8 + j, ag[i][j]);
-          atomicAdd(dbeta + idx * 8 + j, ab[i][j]);
+            for (int j = 0; j < 8; ++j) {
+              if (w == 0) { red[0][idx * 8 + j] = ag[i][j]; red[1][idx * 8 + j] = ab[i][j]; }
+              else { red[0][idx * 8 + j] += ag[i][j]; red[1][idx * 8 + j] += ab[i][j]; }
+            }
+          }
         }
       }
+      __syncthreads();
+    }
+    // blocks start at staggered columns so concurrent blocks add into different words
+    const int rot = (blockIdx.x * 64) % D;
+    for (int c0 = threadIdx.x; c0 < D; c0 += 256) {
+      int c = c0 + rot;
+      if (c >= D) c -= D;
+      atomicAdd(dgamma + c, red[0][c]);
+      atomicAdd(dbeta + c, red[1][c]);
     }
   }
 }
@@ -243,7 +261,7 @@ extern "C" int zk_layernorm_bwd(const void* dy, const void* x, const void* gamma
   if (!dy || !x || !gamma || !mean || !rstd || bad_dim(rows, D) || D > 4096) return ZK_EINVAL;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return ZK_EINVAL;
   int64_t nb = (rows + 3) / 4;
-  if (nb > 512) nb = 512;
+  if (nb > 256) nb = 256;   // one block per CU; every block ends with D atomics per affine vector
   dim3 grid((unsigned)nb), block(256);
 #define CALL(V) hipLaunchKernelGGL((layernorm_bwd_kernel<V>), grid, block, 0, stream, (const bf16_t*)dy, \
     (const bf16_t*)x, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, (int)rows, (int)D)
