@@ -56,6 +56,10 @@ int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, in
                  const void* aux_in, int64_t ldaux, float alpha, const float* alpha_dev,
                  int accumulate, hipStream_t stream);
 
+/* Tuning hook (no counterpart in the reference): force the block tile of zk_gemm_bf16.
+ * -1 = built-in cost model (default), 0 = 128x128, 1 = 256x128, 2 = 256x256. */
+int zk_gemm_set_tile(int cfg);
+
 /* ---- fused attention ----------------------------------------------------------------
  * softmax(Q K^T * scale [+ causal mask]) V, flash-style (no S x S matrix in HBM).
  * Replaces F.scaled_dot_product_attention as called by

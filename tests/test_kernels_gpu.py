@@ -26,15 +26,23 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 # ------------------------------------------------------------------ GEMM
+@pytest.fixture(params=[-1, 0, 1, 2], ids=["auto", "t128", "t256x128", "t256"])
+def gemm_tile(request):
+    """Every GEMM test runs under the cost model and under each forced block tile."""
+    ops.set_gemm_tile(request.param)
+    yield request.param
+    ops.set_gemm_tile(-1)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (577 * 3, 1024, 640), (130, 72, 40), (64, 3072, 1024)])
-def test_gemm_nt(M, N, K):
+def test_gemm_nt(M, N, K, gemm_tile):
     a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
     c = ops.gemm(a, b)
     ref = a.float() @ b.float().t()
     assert relerr(c, ref) < 6e-3
 
 
-def test_gemm_layout_exact_integers():
+def test_gemm_layout_exact_integers(gemm_tile):
     # A = identity-like probe with an ASYMMETRIC B catches any row/col swap or k permutation
     M = N = K = 128
     a = torch.eye(M, K, device=DEV).to(torch.bfloat16)
@@ -49,7 +57,7 @@ def test_gemm_layout_exact_integers():
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 264, 136), (1154, 1024, 4096)])
-def test_gemm_transb_dgrad(M, N, K):
+def test_gemm_transb_dgrad(M, N, K, gemm_tile):
     # dx[M,N] = dy[M,K] @ W[K,N]  (W stored [out=K, in=N]: n contiguous)
     dy, w = rnd(M, K, seed=3), rnd(K, N, seed=4)
     c = ops.gemm(dy, w, trans_b=True)
@@ -57,7 +65,7 @@ def test_gemm_transb_dgrad(M, N, K):
 
 
 @pytest.mark.parametrize("T,No,Ki", [(128, 128, 128), (577 * 2, 264, 136), (1000, 1024, 1024)])
-def test_gemm_wgrad(T, No, Ki):
+def test_gemm_wgrad(T, No, Ki, gemm_tile):
     # dW[No,Ki] = dY[T,No]^T @ X[T,Ki]
     dy, x = rnd(T, No, seed=5), rnd(T, Ki, seed=6)
     c = ops.gemm(dy, x, trans_a=True, trans_b=True)
@@ -66,13 +74,13 @@ def test_gemm_wgrad(T, No, Ki):
     assert relerr(c2, 2 * (dy.float().t() @ x.float())) < 1e-2
 
 
-def test_gemm_transa_only():
+def test_gemm_transa_only(gemm_tile):
     a, b = rnd(200, 136, seed=7), rnd(72, 200, seed=8)   # A stored [K=200][M=136], B [N=72][K=200]
     c = ops.gemm(a, b, trans_a=True)
     assert relerr(c, a.float().t() @ b.float().t()) < 6e-3
 
 
-def test_gemm_strided_views():
+def test_gemm_strided_views(gemm_tile):
     buf = rnd(300, 512, seed=9)
     a = buf[:, 128:384]                       # [300,256] view, lda 512
     w = rnd(264, 256, seed=10)
@@ -83,7 +91,7 @@ def test_gemm_strided_views():
     assert outbuf[:, :512].abs().max() == 0 and outbuf[:, 776:].abs().max() == 0
 
 
-def test_gemm_epilogues():
+def test_gemm_epilogues(gemm_tile):
     M, N, K = 300, 264, 136
     a, w, bias, res = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=0.1), rnd(N, seed=13), rnd(M, N, seed=14)
     pre = a.float() @ w.float().t() + bias.float()

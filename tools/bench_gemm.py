@@ -1,0 +1,57 @@
+"""GEMM micro-benchmark on the shapes of the C3 step (random bf16 data), per tile config.
+    python tools/bench_gemm.py            (on the GPU box)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from zero_amd import ops
+
+M = 6144
+SHAPES = [  # (name, M, N, K, trans_a, trans_b)
+    ("dec qkv    NT", M, 5120, 3072, False, False),
+    ("dec o      NT", M, 3072, 3072, False, False),
+    ("dec gateup NT", M, 16384, 3072, False, False),
+    ("dec down   NT", M, 3072, 8192, False, False),
+    ("dec d_down NN", M, 8192, 3072, False, True),
+    ("dec d_gu   NN", M, 3072, 16384, False, True),
+    ("dec d_qkv  NN", M, 3072, 5120, False, True),
+    ("enc qkv    NT", 4616, 3072, 1024, False, False),
+    ("enc fc1    NT", 4616, 4096, 1024, False, False),
+    ("enc fc2    NT", 4616, 1024, 4096, False, False),
+    ("enc wg fc1 TN", 4096, 1024, 4616, True, True),
+    ("enc wg qkv TN", 3072, 1024, 4616, True, True),
+    ("enc wg o   TN", 1024, 1024, 4616, True, True),
+    ("lm head    NT", 1024, 128256, 3072, False, False),
+    ("lm dgrad   NN", 1024, 3072, 128256, False, True),
+]
+
+
+def main():
+    torch.manual_seed(0)
+    for name, m, n, k, ta, tb in SHAPES:
+        a = torch.randn((k, m) if ta else (m, k), device="cuda").to(torch.bfloat16)
+        b = torch.randn((k, n) if tb else (n, k), device="cuda").to(torch.bfloat16)
+        out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
+        line = f"{name}  M={m:6d} N={n:6d} K={k:6d} :"
+        for cfg, stg in ((0, 10), (0, 11), (1, 11), (2, 10), (2, 11), (-1, 11)):
+            if stg == 10 and not (ta or tb):
+                continue
+            ops.set_gemm_tile(stg)
+            ops.set_gemm_tile(cfg)
+            for _ in range(3):
+                ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            iters = 20
+            e0.record()
+            for _ in range(iters):
+                ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / iters
+            line += f"  t{cfg:2d}{'d' if stg == 10 else 'r'}: {2.0 * m * n * k / ms / 1e9:7.1f} TF ({ms * 1e3:6.0f} us)"
+        print(line, flush=True)
+    ops.set_gemm_tile(-1)
+    ops.set_gemm_tile(11)
+
+
+if __name__ == "__main__":
+    main()

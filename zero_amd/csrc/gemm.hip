@@ -10,21 +10,25 @@
 //   transB == 0 : B is [N][ldb], k contiguous          (nn.Linear weight [out,in] in y = x W^T)
 //   transB == 1 : B is [K][ldb], n contiguous          (W [K=out][N=in] in dx = dy W;  x in dW = dY^T x)
 //
-// Tiling: 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave 64x64 as 4x4
-// v_mfma_f32_16x16x32_bf16 tiles.  Operand tiles are staged HBM -> VGPR -> LDS
-// (double-buffered, the next tile's loads are in flight during the MFMAs).  k-contiguous
-// tiles are stored as [row][64k] with a 16-byte-chunk XOR swizzle and read with
-// ds_read_b128; mn-contiguous tiles are stored as [k][128] and read with
-// ds_read_b64_tr_b16 (the CDNA4 transposed LDS read), so the dgrad/wgrad variants need no
-// transposed copies in HBM.  The MFMA is issued with the operands swapped (D = B_frag x
+// Structure: block tile BM x BN x 64 with 16x16x32 bf16 MFMAs; three instantiations
+//   256x256 (8 waves, 128x64 per wave), 256x128 (8 waves, 64x64), 128x128 (4 waves, 64x64),
+// chosen per problem by a tile-quantisation cost model (256 CUs, one 8-wave block or two
+// 4-wave blocks per CU).  Operand tiles go HBM/L2 -> LDS directly with
+// buffer_load_dwordx4 ... lds (LDS-DMA: no VGPR staging, no ds_write; out-of-range lanes are
+// zero-filled by the buffer bounds check, which is how ragged M/N/K edges are handled).  The LDS
+// image is lane-linear per wave-instruction (1 KiB), so the bank-conflict swizzle is applied to
+// the per-lane SOURCE address and again on the read.  Two LDS stages: the DMA of K-tile t+1 is
+// in flight while tile t feeds the MFMAs; one barrier per K-tile.
+// k-contiguous tiles are [row][64k] images read with ds_read_b128; mn-contiguous tiles are
+// [k][BM|BN] images read with ds_read_b64_tr_b16 (CDNA4 transposed LDS read), so dgrad/wgrad
+// need no transposed copies in HBM.  The MFMA is issued with swapped operands (D = B_frag x
 // A_frag) so each lane ends up with 4 consecutive n of one m: 8-byte C stores.
 #include "common.h"
 #include "../../include/zero_hip.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
+constexpr int BK = 64;
 
 struct GemmArgs {
   const bf16_t* A;
@@ -57,47 +61,63 @@ __device__ __forceinline__ float dact_gelu_erf(float x) {
   return cdf + x * pdf;
 }
 
-// Issue the 4 x 16-byte global loads of one operand tile for this thread.
-template <bool T>
-__device__ __forceinline__ void tile_load(u32x4 (&r)[4], __amdgpu_buffer_rsrc_t rs, int ld, int mn0, int MN,
-                                          int k0, int K, int tid) {
+// LDS-DMA of one operand tile (R rows|cols x 64 k).  Slot s (16 bytes) of the image is filled by
+// thread s % NT in its (s / NT)-th instruction; a wave-instruction fills 64 consecutive slots.
+//   !T : image [R][64k], 8 slots per row; slot (row, pos) holds k-chunk  pos ^ (row & 7)
+//    T : image [64k][R],  R/8 slots per k-row; slot (k, pos) holds mn-chunk  pos ^ swz_t(k)
+template <bool T, int R, int NT>
+__device__ __forceinline__ void tile_dma(__amdgpu_buffer_rsrc_t rs, unsigned char* lds, int ld, int mn0, int MN, int k0,
+                                         int K, int tid) {
+  constexpr int N = R * 8 / NT;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int c = tid + 256 * i;
+  for (int i = 0; i < N; ++i) {
+    const int s = tid + NT * i;
     unsigned int off;
     bool ok;
     if (!T) {
-      int row = c >> 3, kc = c & 7;
+      const int row = s >> 3, kc = (s & 7) ^ (row & 7);
       ok = (mn0 + row < MN) && (k0 + kc * 8 < K);
       off = (unsigned int)(row * ld + k0 + kc * 8) * 2u;
     } else {
-      int kr = c >> 4, ch = c & 15;
+      constexpr int CPR = R / 8;
+      const int kr = s / CPR, ch = (s % CPR) ^ swz_t(kr);
       ok = (k0 + kr < K) && (mn0 + ch * 8 < MN);
       off = (unsigned int)((k0 + kr) * ld + ch * 8) * 2u;
     }
-    r[i] = buf_load16(rs, ok ? off : 0xFFFFFFF0u);
+    // wave-uniform LDS base of this wave-instruction; the hardware adds lane * 16
+    unsigned char* dst = lds + ((tid & ~63) + NT * i) * 16;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16,
+                                             ok ? off : 0xFFFFFFF0u, 0, 0, 0);
   }
 }
 
-template <bool T>
-__device__ __forceinline__ void tile_store_lds(const u32x4 (&r)[4], unsigned char* lds, int tid) {
+// Register-staged alternative for the transposed ([k][R]) image: global -> VGPR (issued before the
+// MFMAs of the current tile) and VGPR -> LDS (after them).  Same image as tile_dma<true>.
+template <int R, int NT>
+__device__ __forceinline__ void tile_load_regs(u32x4 (&r)[R * 8 / NT], __amdgpu_buffer_rsrc_t rs, int ld, int mn0,
+                                               int MN, int k0, int K, int tid) {
+  constexpr int N = R * 8 / NT, CPR = R / 8;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int c = tid + 256 * i;
-    int addr;
-    if (!T) {
-      int row = c >> 3, kc = c & 7;
-      addr = row * 128 + ((kc ^ (row & 7)) << 4);
-    } else {
-      int kr = c >> 4, ch = c & 15;
-      addr = kr * 256 + ((ch ^ swz_t(kr)) << 4);
-    }
-    *reinterpret_cast<u32x4*>(lds + addr) = r[i];
+  for (int i = 0; i < N; ++i) {
+    const int s = tid + NT * i;
+    const int kr = s / CPR, ch = s % CPR;
+    const bool ok = (k0 + kr < K) && (mn0 + ch * 8 < MN);
+    r[i] = buf_load16(rs, ok ? (unsigned int)((k0 + kr) * ld + ch * 8) * 2u : 0xFFFFFFF0u);
+  }
+}
+template <int R, int NT>
+__device__ __forceinline__ void tile_store_regs(const u32x4 (&r)[R * 8 / NT], unsigned char* lds, int tid) {
+  constexpr int N = R * 8 / NT, CPR = R / 8;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int s = tid + NT * i;
+    const int kr = s / CPR, ch = s % CPR;
+    *reinterpret_cast<u32x4*>(lds + kr * (R * 2) + ((ch ^ swz_t(kr)) << 4)) = r[i];
   }
 }
 
-// One 16(mn) x 32(k) MFMA operand fragment for k-step kk from the LDS tile.
-template <bool T>
+// One 16(mn) x 32(k) MFMA operand fragment for k-step kk from the LDS image.
+template <bool T, int R>
 __device__ __forceinline__ bf16x8 frag_load(const unsigned char* lds, int mn_base, int kk, int lane) {
   if (!T) {
     int row = mn_base + (lane & 15);
@@ -111,8 +131,8 @@ __device__ __forceinline__ bf16x8 frag_load(const unsigned char* lds, int mn_bas
     int sub = (mn & 7) * 2;
     int k0r = kk * 32 + 8 * g + q;
     int k1r = k0r + 4;
-    short4_t lo = lds_read_tr16(lds + k0r * 256 + ((ch ^ swz_t(k0r)) << 4) + sub);
-    short4_t hi = lds_read_tr16(lds + k1r * 256 + ((ch ^ swz_t(k1r)) << 4) + sub);
+    short4_t lo = lds_read_tr16(lds + k0r * (R * 2) + ((ch ^ swz_t(k0r)) << 4) + sub);
+    short4_t hi = lds_read_tr16(lds + k1r * (R * 2) + ((ch ^ swz_t(k1r)) << 4) + sub);
     union { struct { short4_t a, b; } s; bf16x8 v; } u;
     u.s.a = lo;
     u.s.b = hi;
@@ -120,13 +140,16 @@ __device__ __forceinline__ bf16x8 frag_load(const unsigned char* lds, int mn_bas
   }
 }
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+template <bool TA, bool TB, int BM, int BN, int WAVES_M, int WAVES_N, int STG>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(GemmArgs g) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
+  constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = (BM + BN) * BK * 2;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   // XCD-aware, bijective block remap (blocks b and b+8 share an XCD / L2), then a banded
   // tile order (8 m-tiles per band, m fastest) so co-resident blocks share B panels in L2.
@@ -149,47 +172,56 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   __amdgpu_buffer_rsrc_t rA = make_rsrc(Ab, 0x7FFFFFF0u);
   __amdgpu_buffer_rsrc_t rB = make_rsrc(Bb, 0x7FFFFFF0u);
 
-  f32x4 acc[4][4];
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[4], rb[4];
+  // STG == 1: transposed operands are staged through registers (ds_write), k-contiguous ones by DMA
+  constexpr bool RA = TA && (STG == 1), RB = TB && (STG == 1);
+  u32x4 ra[RA ? BM * 8 / NT : 1], rb[RB ? BN * 8 / NT : 1];
   const int nk = (g.K + BK - 1) / BK;
-  tile_load<TA>(ra, rA, g.lda, m0, g.M, 0, g.K, tid);
-  tile_load<TB>(rb, rB, g.ldb, n0, g.N, 0, g.K, tid);
-  tile_store_lds<TA>(ra, smem, tid);
-  tile_store_lds<TB>(rb, smem + BM * BK * 2, tid);
+  if constexpr (RA) { tile_load_regs<BM, NT>(ra, rA, g.lda, m0, g.M, 0, g.K, tid); tile_store_regs<BM, NT>(ra, smem, tid); }
+  else tile_dma<TA, BM, NT>(rA, smem, g.lda, m0, g.M, 0, g.K, tid);
+  if constexpr (RB) { tile_load_regs<BN, NT>(rb, rB, g.ldb, n0, g.N, 0, g.K, tid); tile_store_regs<BN, NT>(rb, smem + A_BYTES, tid); }
+  else tile_dma<TB, BN, NT>(rB, smem + A_BYTES, g.ldb, n0, g.N, 0, g.K, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int t = 0; t < nk; ++t) {
-    unsigned char* cur = smem + (t & 1) * STAGE_BYTES;
+    const unsigned char* la = smem + (t & 1) * STAGE_BYTES;
+    const unsigned char* lb = la + A_BYTES;
     unsigned char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
-    const bool more = (t + 1 < nk);
+    const bool more = t + 1 < nk;
     if (more) {
-      tile_load<TA>(ra, rA, g.lda, m0, g.M, (t + 1) * BK, g.K, tid);
-      tile_load<TB>(rb, rB, g.ldb, n0, g.N, (t + 1) * BK, g.K, tid);
+      if constexpr (RA) tile_load_regs<BM, NT>(ra, rA, g.lda, m0, g.M, (t + 1) * BK, g.K, tid);
+      else tile_dma<TA, BM, NT>(rA, nxt, g.lda, m0, g.M, (t + 1) * BK, g.K, tid);
+      if constexpr (RB) tile_load_regs<BN, NT>(rb, rB, g.ldb, n0, g.N, (t + 1) * BK, g.K, tid);
+      else tile_dma<TB, BN, NT>(rB, nxt + A_BYTES, g.ldb, n0, g.N, (t + 1) * BK, g.K, tid);
     }
-    const unsigned char* la = cur;
-    const unsigned char* lb = cur + BM * BK * 2;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fb[4];
+      bf16x8 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = frag_load<TA>(la, wm * 64 + i * 16, kk, lane);
+      for (int j = 0; j < TN; ++j) fb[j] = frag_load<TB, BN>(lb, wn * (TN * 16) + j * 16, kk, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = frag_load<TB>(lb, wn * 64 + j * 16, kk, lane);
+      for (int i = 0; i < TM; ++i) fa[i] = frag_load<TA, BM>(la, wm * (TM * 16) + i * 16, kk, lane);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
     if (more) {
-      tile_store_lds<TA>(ra, nxt, tid);
-      tile_store_lds<TB>(rb, nxt + BM * BK * 2, tid);
+      if constexpr (RA) tile_store_regs<BM, NT>(ra, nxt, tid);
+      if constexpr (RB) tile_store_regs<BN, NT>(rb, nxt + A_BYTES, tid);
     }
+    // the DMA of tile t+1 must have landed (every wave waits for its own pieces) before any wave
+    // reads it, and every wave must be done reading tile t before it is overwritten at t+2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
@@ -198,12 +230,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   if (g.alpha_dev) alpha *= *g.alpha_dev;
   const int epi = g.epilogue;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (TM * 16) + i * 16 + (lane & 15);
     if (m >= g.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (TN * 16) + j * 16 + (lane >> 4) * 4;
       if (n >= g.N) continue;
       float v[4];
 #pragma unroll
@@ -249,6 +281,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
 }  // namespace
 
+namespace {
+int g_force_tile = -1;   // tuning hook: -1 = cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256
+int g_stage_mode = 1;    // tuning hook: 0 = LDS-DMA for every operand, 1 = registers for transposed operands
+
+template <int BM, int BN, int WM_, int WN_>
+void launch_cfg(const GemmArgs& g0, int transA, int transB, hipStream_t stream) {
+  GemmArgs g = g0;
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  dim3 grid(g.tiles_m * g.tiles_n), block(64 * WM_ * WN_);
+  const bool reg = g_stage_mode == 1;
+#define ZK_LAUNCH(TA_, TB_, STG_) hipLaunchKernelGGL((gemm_kernel<TA_, TB_, BM, BN, WM_, WN_, STG_>), grid, block, 0, stream, g)
+  if (!transA && !transB) ZK_LAUNCH(false, false, 0);
+  else if (!transA && transB) { if (reg) ZK_LAUNCH(false, true, 1); else ZK_LAUNCH(false, true, 0); }
+  else if (transA && transB) { if (reg) ZK_LAUNCH(true, true, 1); else ZK_LAUNCH(true, true, 0); }
+  else { if (reg) ZK_LAUNCH(true, false, 1); else ZK_LAUNCH(true, false, 0); }
+#undef ZK_LAUNCH
+}
+
+// Tile choice: time ~ rounds(tiles / concurrent blocks) x tile area / relative efficiency.
+int choose_tile(int64_t M, int64_t N) {
+  if (g_force_tile >= 0) return g_force_tile;
+  const int bm[3] = {128, 256, 256}, bn[3] = {128, 128, 256};
+  const double slots[3] = {512.0, 256.0, 256.0};      // two 4-wave blocks or one 8-wave block per CU
+  const double eff[3] = {1.0, 0.85, 1.02};            // measured on MI355X (tools/bench_gemm.py), 2-stage LDS-DMA pipeline
+  int best = 0;
+  double best_cost = 1e300;
+  for (int c = 0; c < 3; ++c) {
+    double tiles = (double)((M + bm[c] - 1) / bm[c]) * (double)((N + bn[c] - 1) / bn[c]);
+    double rounds = (double)(int64_t)((tiles + slots[c] - 1) / slots[c]);
+    double cost = rounds * slots[c] * bm[c] * bn[c] / eff[c];
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+}  // namespace
+
+extern "C" int zk_gemm_set_tile(int cfg) {
+  // cfg in [-1, 2] selects the tile; cfg = 10 / 11 selects the staging mode (0 / 1)
+  if (cfg == 10 || cfg == 11) { g_stage_mode = cfg - 10; return ZK_OK; }
+  if (cfg < -1 || cfg > 2) return ZK_EINVAL;
+  g_force_tile = cfg;
+  return ZK_OK;
+}
+
 extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                             int64_t ldb, int64_t ldc, int transA, int transB, int epilogue, const void* bias,
                             const void* residual, int64_t ldr, void* aux_out, const void* aux_in, int64_t ldaux,
@@ -264,7 +341,7 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) return ZK_EINVAL;
   if (reinterpret_cast<uintptr_t>(C) & 7) return ZK_EINVAL;
   // 32-bit byte offsets inside one block tile
-  if ((transA ? K : 128) * lda * 2 >= 0x7FFFFFF0LL || (transB ? K : 128) * ldb * 2 >= 0x7FFFFFF0LL) return ZK_EINVAL;
+  if ((transA ? K : 256) * lda * 2 >= 0x7FFFFFF0LL || (transB ? K : 256) * ldb * 2 >= 0x7FFFFFF0LL) return ZK_EINVAL;
   GemmArgs g;
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = (bf16_t*)C;
   g.bias = (const bf16_t*)bias; g.residual = (const bf16_t*)residual;
@@ -273,13 +350,12 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
   g.lda = (int)lda; g.ldb = (int)ldb; g.ldc = (int)ldc; g.ldr = (int)ldr; g.ldaux = (int)ldaux;
   g.epilogue = epilogue; g.accumulate = accumulate;
-  g.tiles_m = (int)((M + BM - 1) / BM);
-  g.tiles_n = (int)((N + BN - 1) / BN);
-  dim3 grid(g.tiles_m * g.tiles_n), block(256);
-  if (!transA && !transB) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, stream, g);
-  else if (!transA && transB) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, stream, g);
-  else if (transA && transB) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, stream, g);
-  else hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, stream, g);
+  g.tiles_m = g.tiles_n = 0;
+  switch (choose_tile(M, N)) {
+    case 2: launch_cfg<256, 256, 2, 4>(g, transA, transB, stream); break;
+    case 1: launch_cfg<256, 128, 4, 2>(g, transA, transB, stream); break;
+    default: launch_cfg<128, 128, 2, 2>(g, transA, transB, stream); break;
+  }
   ZK_CHECK_LAUNCH();
   return ZK_OK;
 }

@@ -259,3 +259,8 @@ def f32_to_bf16_(src, dst, scale: float = 1.0, accumulate: bool = False):
     check(lib.zk_f32_to_bf16(_p(src), _p(dst), src.numel(), float(scale), int(accumulate), _stream()),
           "zk_f32_to_bf16")
     return dst
+
+
+def set_gemm_tile(cfg: int = -1):
+    """Tuning hook: force the GEMM block tile (-1 cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256)."""
+    check(lib.zk_gemm_set_tile(int(cfg)), "zk_gemm_set_tile")
