@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 8; 64 for c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--gemm-shapes", action="store_true", help="per-shape GEMM table on stderr")
     return ap.parse_args()
 
 
@@ -181,6 +182,14 @@ def main():
         for key, fl, e0, e1, shp in records:
             d = fam.setdefault(key, dict(n=0, ms=0.0, flops=0.0))
             d["n"] += 1; d["ms"] += e0.elapsed_time(e1); d["flops"] += fl
+        if args.gemm_shapes:
+            shp = {}
+            for k_, fl, e0, e1, mnk in records:
+                d_ = shp.setdefault((k_, mnk), [0, 0.0, fl])
+                d_[0] += 1; d_[1] += e0.elapsed_time(e1)
+            for (k_, mnk), (n_, ms_, fl) in sorted(shp.items(), key=lambda kv: -kv[1][1]):
+                print(f"  tA{int(k_[0])}tB{int(k_[1])} M,N,K={mnk}  x{n_ // 2:3d}/step  {ms_ / 2:7.2f} ms/step  "
+                      f"{fl * n_ / (ms_ * 1e-3) / 1e12:7.1f} TF/s", file=sys.stderr)
         key = max(fam, key=lambda k: fam[k]["ms"])
         d = fam[key]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12

@@ -42,6 +42,9 @@ int zk_abi_version(void);
  * ref:adapter.py:36) with optional copy of the bf16 pre-activation to aux_out;
  * residual add (tf:clip:376,381; tf:llama:306,321); MUL_D*: multiply by the activation
  * derivative at aux_in (backward of the fused activation); accumulate: C += result.
+ * workspace (optional, fp32 scratch owned by the caller): lets plain products with a small
+ * output and a long contraction (weight gradients, lm_head dgrad) run split-K; every split
+ * writes its own slab (no atomics: deterministic), a finishing pass sums them.
  */
 enum {
   ZK_EPI_NONE = 0,
@@ -54,10 +57,12 @@ int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, in
                  int64_t lda, int64_t ldb, int64_t ldc, int transA, int transB, int epilogue,
                  const void* bias, const void* residual, int64_t ldr, void* aux_out,
                  const void* aux_in, int64_t ldaux, float alpha, const float* alpha_dev,
-                 int accumulate, hipStream_t stream);
+                 int accumulate, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* Tuning hook (no counterpart in the reference): force the block tile of zk_gemm_bf16.
- * -1 = built-in cost model (default), 0 = 128x128, 1 = 256x128, 2 = 256x256. */
+ * -1 = built-in cost model (default), 0 = 128x128, 1 = 256x128, 2 = 256x256;
+ * 10/11 = LDS-DMA for all operands / registers for transposed ones (default);
+ * 100 = split-K heuristic (default), 101 = no split-K, 102..116 = force that many splits. */
 int zk_gemm_set_tile(int cfg);
 
 /* ---- fused attention ----------------------------------------------------------------

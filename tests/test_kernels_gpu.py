@@ -26,7 +26,7 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.fixture(params=[-1, 0, 1, 2], ids=["auto", "t128", "t256x128", "t256"])
+@pytest.fixture(params=[-1, 0, 1, 2, 3], ids=["auto", "t128", "t256x128", "t256", "t128x96"])
 def gemm_tile(request):
     """Every GEMM test runs under the cost model and under each forced block tile."""
     ops.set_gemm_tile(request.param)
@@ -120,6 +120,29 @@ def test_gemm_epilogues(gemm_tile):
     F.gelu(hf).sum().backward()
     got = ops.gemm(dyy, w2, trans_b=True, epilogue=ops.EPI_MUL_DGELU_ERF, aux_in=h)
     assert relerr(got, base * hf.grad) < 8e-3
+
+
+@pytest.mark.parametrize("splits", [100, 102, 105, 116])
+def test_gemm_split_k(splits):
+    """Small output + long contraction: fp32 slabs per split + finishing pass (wgrad / lm_head dgrad)."""
+    ops.set_gemm_tile(splits)
+    try:
+        dy, x = rnd(4616, 264, seed=5), rnd(4616, 136, seed=6)            # wgrad, ragged K tail
+        ref = dy.float().t() @ x.float()
+        c = ops.gemm(dy, x, trans_a=True, trans_b=True)
+        assert relerr(c, ref) < 6e-3
+        c2 = ops.gemm(dy, x, trans_a=True, trans_b=True, out=c.clone(), accumulate=True)
+        assert relerr(c2, 2 * ref) < 1e-2
+        a, w = rnd(300, 8200, seed=7), rnd(8200, 520, seed=8, scale=0.05)   # dgrad over a long K
+        al = torch.tensor([0.5], device=DEV)
+        out = torch.zeros(300, 1024, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(a, w, trans_b=True, alpha_dev=al, out=out[:, 8:528])
+        assert relerr(out[:, 8:528], 0.5 * (a.float() @ w.float())) < 6e-3
+        assert out[:, :8].abs().max() == 0 and out[:, 528:].abs().max() == 0
+        b2 = rnd(520, 8200, seed=9, scale=0.05)                              # NT over a long K
+        assert relerr(ops.gemm(a, b2), a.float() @ b2.float().t()) < 6e-3
+    finally:
+        ops.set_gemm_tile(100)
 
 
 def test_gemm_rejects_bad_shapes():

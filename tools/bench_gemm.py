@@ -32,7 +32,7 @@ def main():
         b = torch.randn((k, n) if tb else (n, k), device="cuda").to(torch.bfloat16)
         out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
         line = f"{name}  M={m:6d} N={n:6d} K={k:6d} :"
-        for cfg, stg in ((0, 10), (0, 11), (1, 11), (2, 10), (2, 11), (-1, 11)):
+        for cfg, stg in ((0, 10), (0, 11), (1, 11), (2, 10), (2, 11), (3, 11), (-1, 11)):
             if stg == 10 and not (ta or tb):
                 continue
             ops.set_gemm_tile(stg)
@@ -48,6 +48,18 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / iters
             line += f"  t{cfg:2d}{'d' if stg == 10 else 'r'}: {2.0 * m * n * k / ms / 1e9:7.1f} TF ({ms * 1e3:6.0f} us)"
+        ops.set_gemm_tile(101)
+        for _ in range(3):
+            ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        line += f"  nosplit: {2.0 * m * n * k / ms / 1e9:7.1f} TF ({ms * 1e3:6.0f} us)"
+        ops.set_gemm_tile(100)
         print(line, flush=True)
     ops.set_gemm_tile(-1)
     ops.set_gemm_tile(11)

@@ -22,7 +22,7 @@ _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 # name -> argtypes, in the order of include/zero_hip.h
 SIGNATURES = {
     "zk_abi_version": [],
-    "zk_gemm_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _P, _P, _L, _P, _P, _L, _F, _P, _I, _P],
+    "zk_gemm_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _P, _P, _L, _P, _P, _L, _F, _P, _I, _P, _L, _P],
     "zk_gemm_set_tile": [_I],
     "zk_attn_fwd": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "zk_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],

@@ -12,6 +12,9 @@
 //
 // Structure: block tile BM x BN x 64 with 16x16x32 bf16 MFMAs; three instantiations
 //   256x256 (8 waves, 128x64 per wave), 256x128 (8 waves, 64x64), 128x128 (4 waves, 64x64),
+//   128x96 (4 waves, 64x48: N = 3072 at M = 6144 is 1536 tiles = exactly 3 rounds of 512 slots),
+// plus split-K (fp32 slabs in a caller-provided workspace + a finishing pass) for small outputs
+// with long contractions (weight gradients, lm_head dgrad),
 // chosen per problem by a tile-quantisation cost model (256 CUs, one 8-wave block or two
 // 4-wave blocks per CU).  Operand tiles go HBM/L2 -> LDS directly with
 // buffer_load_dwordx4 ... lds (LDS-DMA: no VGPR staging, no ds_write; out-of-range lanes are
@@ -45,6 +48,8 @@ struct GemmArgs {
   int epilogue;
   int accumulate;  // C += result
   int tiles_m, tiles_n;
+  int splits, kchunk;      // split-K: block (tile, s) covers k in [s*kchunk, min(K, (s+1)*kchunk))
+  float* slab;             // [splits][M][N] fp32 partial results (split-K only)
 };
 
 __device__ __forceinline__ int swz_t(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
@@ -154,7 +159,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(GemmArgs g
   // XCD-aware, bijective block remap (blocks b and b+8 share an XCD / L2), then a banded
   // tile order (8 m-tiles per band, m fastest) so co-resident blocks share B panels in L2.
   const int nwg = g.tiles_m * g.tiles_n;
-  int bid = blockIdx.x;
+  const int split = blockIdx.x / nwg;
+  int bid = blockIdx.x - split * nwg;
   {
     int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -181,11 +187,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(GemmArgs g
   // STG == 1: transposed operands are staged through registers (ds_write), k-contiguous ones by DMA
   constexpr bool RA = TA && (STG == 1), RB = TB && (STG == 1);
   u32x4 ra[RA ? BM * 8 / NT : 1], rb[RB ? BN * 8 / NT : 1];
-  const int nk = (g.K + BK - 1) / BK;
-  if constexpr (RA) { tile_load_regs<BM, NT>(ra, rA, g.lda, m0, g.M, 0, g.K, tid); tile_store_regs<BM, NT>(ra, smem, tid); }
-  else tile_dma<TA, BM, NT>(rA, smem, g.lda, m0, g.M, 0, g.K, tid);
-  if constexpr (RB) { tile_load_regs<BN, NT>(rb, rB, g.ldb, n0, g.N, 0, g.K, tid); tile_store_regs<BN, NT>(rb, smem + A_BYTES, tid); }
-  else tile_dma<TB, BN, NT>(rB, smem + A_BYTES, g.ldb, n0, g.N, 0, g.K, tid);
+  const int kb = split * g.kchunk;
+  const int Ke = min(g.K, kb + g.kchunk);
+  const int nk = (Ke - kb + BK - 1) / BK;
+  if constexpr (RA) { tile_load_regs<BM, NT>(ra, rA, g.lda, m0, g.M, kb, Ke, tid); tile_store_regs<BM, NT>(ra, smem, tid); }
+  else tile_dma<TA, BM, NT>(rA, smem, g.lda, m0, g.M, kb, Ke, tid);
+  if constexpr (RB) { tile_load_regs<BN, NT>(rb, rB, g.ldb, n0, g.N, kb, Ke, tid); tile_store_regs<BN, NT>(rb, smem + A_BYTES, tid); }
+  else tile_dma<TB, BN, NT>(rB, smem + A_BYTES, g.ldb, n0, g.N, kb, Ke, tid);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -195,10 +203,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(GemmArgs g
     unsigned char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
     const bool more = t + 1 < nk;
     if (more) {
-      if constexpr (RA) tile_load_regs<BM, NT>(ra, rA, g.lda, m0, g.M, (t + 1) * BK, g.K, tid);
-      else tile_dma<TA, BM, NT>(rA, nxt, g.lda, m0, g.M, (t + 1) * BK, g.K, tid);
-      if constexpr (RB) tile_load_regs<BN, NT>(rb, rB, g.ldb, n0, g.N, (t + 1) * BK, g.K, tid);
-      else tile_dma<TB, BN, NT>(rB, nxt + A_BYTES, g.ldb, n0, g.N, (t + 1) * BK, g.K, tid);
+      if constexpr (RA) tile_load_regs<BM, NT>(ra, rA, g.lda, m0, g.M, kb + (t + 1) * BK, Ke, tid);
+      else tile_dma<TA, BM, NT>(rA, nxt, g.lda, m0, g.M, kb + (t + 1) * BK, Ke, tid);
+      if constexpr (RB) tile_load_regs<BN, NT>(rb, rB, g.ldb, n0, g.N, kb + (t + 1) * BK, Ke, tid);
+      else tile_dma<TB, BN, NT>(rB, nxt + A_BYTES, g.ldb, n0, g.N, kb + (t + 1) * BK, Ke, tid);
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -225,6 +233,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(GemmArgs g
     __syncthreads();
   }
 
+  // ---- split-K: plain 16-byte fp32 stores into this split's slab; zk_splitk_finish sums the slabs
+  if (g.splits > 1) {
+    float* slab = g.slab + (size_t)split * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * (TM * 16) + i * 16 + (lane & 15);
+      if (m >= g.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (TN * 16) + j * 16 + (lane >> 4) * 4;
+        if (n >= g.N) continue;
+        *reinterpret_cast<f32x4*>(slab + (size_t)m * g.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
   // ---- epilogue: lane holds C[m][n..n+3], m = l&15, n = 4*(l>>4) + reg ----
   float alpha = g.alpha;
   if (g.alpha_dev) alpha *= *g.alpha_dev;
@@ -279,10 +303,38 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(GemmArgs g
   }
 }
 
+// C = bf16(alpha * sum_s slab[s] (+ C)), 4 columns per thread
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* slab, bf16_t* C, int M, int N, int ldc,
+                                                            int splits, float alpha, const float* alpha_dev,
+                                                            int accumulate) {
+  if (alpha_dev) alpha *= *alpha_dev;
+  const int n4 = N >> 2;
+  const int64_t total = (int64_t)M * n4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+    f32x4 a = *reinterpret_cast<const f32x4*>(slab + (size_t)m * N + n);
+    for (int s = 1; s < splits; ++s) {
+      f32x4 b = *reinterpret_cast<const f32x4*>(slab + ((size_t)s * M + m) * N + n);
+      a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+    }
+    bf16_t* cp = C + (size_t)m * ldc + n;
+    float v[4] = {a[0] * alpha, a[1] * alpha, a[2] * alpha, a[3] * alpha};
+    if (accumulate) {
+      u32x2 o = *reinterpret_cast<const u32x2*>(cp);
+      v[0] += lo_bf(o[0]); v[1] += hi_bf(o[0]); v[2] += lo_bf(o[1]); v[3] += hi_bf(o[1]);
+    }
+    u32x2 out;
+    out[0] = pack2bf(v[0], v[1]);
+    out[1] = pack2bf(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(cp) = out;
+  }
+}
+
 }  // namespace
 
 namespace {
 int g_force_tile = -1;   // tuning hook: -1 = cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256
+int g_force_splits = 0;  // tuning hook: 0 = heuristic, 1 = never split K, n > 1 = force n splits
 int g_stage_mode = 1;    // tuning hook: 0 = LDS-DMA for every operand, 1 = registers for transposed operands
 
 template <int BM, int BN, int WM_, int WN_>
@@ -290,25 +342,27 @@ void launch_cfg(const GemmArgs& g0, int transA, int transB, hipStream_t stream) 
   GemmArgs g = g0;
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
-  dim3 grid(g.tiles_m * g.tiles_n), block(64 * WM_ * WN_);
+  dim3 grid(g.tiles_m * g.tiles_n * g.splits), block(64 * WM_ * WN_);
   const bool reg = g_stage_mode == 1;
 #define ZK_LAUNCH(TA_, TB_, STG_) hipLaunchKernelGGL((gemm_kernel<TA_, TB_, BM, BN, WM_, WN_, STG_>), grid, block, 0, stream, g)
   if (!transA && !transB) ZK_LAUNCH(false, false, 0);
-  else if (!transA && transB) { if (reg) ZK_LAUNCH(false, true, 1); else ZK_LAUNCH(false, true, 0); }
-  else if (transA && transB) { if (reg) ZK_LAUNCH(true, true, 1); else ZK_LAUNCH(true, true, 0); }
-  else { if (reg) ZK_LAUNCH(true, false, 1); else ZK_LAUNCH(true, false, 0); }
+  else if (transA && !transB) { if (reg) ZK_LAUNCH(true, false, 1); else ZK_LAUNCH(true, false, 0); }
+  else if constexpr ((BN & (BN - 1)) == 0) {   // the transposed-B image needs a power-of-two row (swizzle)
+    if (!transA) { if (reg) ZK_LAUNCH(false, true, 1); else ZK_LAUNCH(false, true, 0); }
+    else { if (reg) ZK_LAUNCH(true, true, 1); else ZK_LAUNCH(true, true, 0); }
+  }
 #undef ZK_LAUNCH
 }
 
 // Tile choice: time ~ rounds(tiles / concurrent blocks) x tile area / relative efficiency.
-int choose_tile(int64_t M, int64_t N) {
-  if (g_force_tile >= 0) return g_force_tile;
-  const int bm[3] = {128, 256, 256}, bn[3] = {128, 128, 256};
-  const double slots[3] = {512.0, 256.0, 256.0};      // two 4-wave blocks or one 8-wave block per CU
-  const double eff[3] = {1.0, 0.85, 1.02};            // measured on MI355X (tools/bench_gemm.py), 2-stage LDS-DMA pipeline
+int choose_tile(int64_t M, int64_t N, int transB) {
+  if (g_force_tile >= 0) return (g_force_tile == 3 && transB) ? 0 : g_force_tile;
+  const int bm[4] = {128, 256, 256, 128}, bn[4] = {128, 128, 256, 96};
+  const double slots[4] = {512.0, 256.0, 256.0, 512.0};   // two 4-wave blocks or one 8-wave block per CU
+  const double eff[4] = {1.0, 0.85, 1.02, 0.93};          // measured on MI355X (tools/bench_gemm.py)
   int best = 0;
   double best_cost = 1e300;
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < (transB ? 3 : 4); ++c) {
     double tiles = (double)((M + bm[c] - 1) / bm[c]) * (double)((N + bn[c] - 1) / bn[c]);
     double rounds = (double)(int64_t)((tiles + slots[c] - 1) / slots[c]);
     double cost = rounds * slots[c] * bm[c] * bn[c] / eff[c];
@@ -321,7 +375,8 @@ int choose_tile(int64_t M, int64_t N) {
 extern "C" int zk_gemm_set_tile(int cfg) {
   // cfg in [-1, 2] selects the tile; cfg = 10 / 11 selects the staging mode (0 / 1)
   if (cfg == 10 || cfg == 11) { g_stage_mode = cfg - 10; return ZK_OK; }
-  if (cfg < -1 || cfg > 2) return ZK_EINVAL;
+  if (cfg >= 100 && cfg <= 116) { g_force_splits = cfg - 100; return ZK_OK; }   // 100 = heuristic, 101 = off
+  if (cfg < -1 || cfg > 3) return ZK_EINVAL;
   g_force_tile = cfg;
   return ZK_OK;
 }
@@ -329,7 +384,8 @@ extern "C" int zk_gemm_set_tile(int cfg) {
 extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                             int64_t ldb, int64_t ldc, int transA, int transB, int epilogue, const void* bias,
                             const void* residual, int64_t ldr, void* aux_out, const void* aux_in, int64_t ldaux,
-                            float alpha, const float* alpha_dev, int accumulate, hipStream_t stream) {
+                            float alpha, const float* alpha_dev, int accumulate, void* workspace,
+                            int64_t workspace_bytes, hipStream_t stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ZK_EINVAL;
   if ((N & 7) || (ldc & 3)) return ZK_EINVAL;
   if ((!transA || !transB) && (K & 7)) return ZK_EINVAL;  // k-contiguous operands are read in 8-element chunks
@@ -351,7 +407,32 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
   g.lda = (int)lda; g.ldb = (int)ldb; g.ldc = (int)ldc; g.ldr = (int)ldr; g.ldaux = (int)ldaux;
   g.epilogue = epilogue; g.accumulate = accumulate;
   g.tiles_m = g.tiles_n = 0;
-  switch (choose_tile(M, N)) {
+  g.splits = 1; g.kchunk = (int)((K + BK - 1) / BK * BK); g.slab = nullptr;
+  // split-K for small outputs with a long contraction (wgrad, lm_head dgrad): fill the 256 CUs
+  const bool plain = epilogue == ZK_EPI_NONE && !bias && !residual && !aux_out;
+  if (plain && workspace && g_force_splits != 1) {
+    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    int64_t sp = g_force_splits > 1 ? g_force_splits : (tiles <= 300 && K >= 2048 ? 1024 / tiles : 1);
+    if (sp > 16) sp = 16;
+    while (sp > 1 && (K / sp < 512 || sp * M * N * 4 > workspace_bytes)) --sp;
+    if (sp > 1) {
+      g.splits = (int)sp;
+      g.kchunk = (int)(((K + sp - 1) / sp + BK - 1) / BK * BK);
+      g.splits = (int)((K + g.kchunk - 1) / g.kchunk);
+      g.slab = (float*)workspace;
+    }
+  }
+  if (g.splits > 1) {
+    launch_cfg<128, 128, 2, 2>(g, transA, transB, stream);
+    int64_t nb = (M * (N / 4) + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)nb), dim3(256), 0, stream, g.slab, g.C, g.M, g.N, g.ldc,
+                       g.splits, alpha, alpha_dev, accumulate);
+    ZK_CHECK_LAUNCH();
+    return ZK_OK;
+  }
+  switch (choose_tile(M, N, transB)) {
+    case 3: launch_cfg<128, 96, 2, 2>(g, transA, transB, stream); break;
     case 2: launch_cfg<256, 256, 2, 4>(g, transA, transB, stream); break;
     case 1: launch_cfg<256, 128, 4, 2>(g, transA, transB, stream); break;
     default: launch_cfg<128, 128, 2, 2>(g, transA, transB, stream); break;

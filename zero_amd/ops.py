@@ -39,6 +39,18 @@ def _chk_flat(t: torch.Tensor, name: str, dtype=BF16):
         raise ValueError(f"{name}: expected a contiguous {dtype} ROCm tensor")
 
 
+_WORKSPACE = {}
+WORKSPACE_BYTES = 160 << 20
+
+
+def _workspace(device) -> torch.Tensor:
+    """Per-device fp32 scratch for split-K GEMMs, allocated once (the C ABI never allocates)."""
+    ws = _WORKSPACE.get(device)
+    if ws is None:
+        ws = _WORKSPACE[device] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+    return ws
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
          out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
          residual: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
@@ -79,7 +91,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
         _chk_flat(alpha_dev, "alpha_dev", torch.float32)
     rc = lib.zk_gemm_bf16(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0),
                           int(trans_a), int(trans_b), epilogue, _p(bias), _p(residual), ldr, _p(aux_out),
-                          _p(aux_in), ldaux, float(alpha), _p(alpha_dev), int(accumulate), _stream())
+                          _p(aux_in), ldaux, float(alpha), _p(alpha_dev), int(accumulate),
+                          _workspace(a.device).data_ptr(), WORKSPACE_BYTES, _stream())
     check(rc, f"zk_gemm_bf16 M={M} N={N} K={K} tA={trans_a} tB={trans_b}")
     return out
 
