@@ -1,0 +1,109 @@
+"""N > 1 path on CPU: world_size-2 gloo process group, 127.0.0.1 rendezvous.
+Covers reduce_sum / reduce_sum_pair (forward SUM, identity backward: SURVEY.md Q2) and the flat
+bucketed gradient reducer (bucket launch on last slot written, no_sync accumulation, zero fill of
+unwritten slots).  The wgrad kernels themselves need a GPU, so the slots are filled by hand the way
+functional.GradSink does it."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from zero_amd.distributed.ddp import FlatGradReducer
+        from zero_amd.distributed.torchshard import reduce_sum, reduce_sum_pair
+        from zero_amd.functional import GradSink
+        from zero_amd.models.layers import Linear, pack_params
+
+        # ---- scalar reductions (engine:308-313)
+        x = torch.tensor(float(rank + 1), requires_grad=True)
+        loss_sum = x * 3.0
+        tot = reduce_sum(loss_sum)
+        ntok = reduce_sum(torch.tensor(10 * (rank + 1)))
+        (tot / ntok).backward()
+        assert tot.item() == 3.0 * (1 + 2) and ntok.item() == 30
+        assert abs(x.grad.item() - 3.0 / 30) < 1e-7          # identity backward: local sum / GLOBAL count
+        y = torch.tensor(float(rank + 1), requires_grad=True)
+        l2, n2 = reduce_sum_pair(y * 3.0, torch.tensor(10 * (rank + 1)))
+        (l2 / n2).backward()
+        assert l2.item() == 9.0 and n2.item() == 30 and abs(y.grad.item() - 0.1) < 1e-7
+
+        # ---- flat reducer
+        class M(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.q, self.k, self.v = Linear(8, 8), Linear(8, 8), Linear(8, 8)
+                pack_params([self.q.weight, self.k.weight, self.v.weight])
+                self.o = Linear(8, 16)
+        torch.manual_seed(0)
+        m = M()
+        r = FlatGradReducer(m, bucket_bytes=256)
+        assert r.world == 2 and len(r.buckets) >= 2
+        params = list(r.params)
+
+        def write(p, val, accumulate):
+            if accumulate and p._zk_dirty:
+                p._zk_grad += val
+            else:
+                p._zk_grad.fill_(val)
+            GradSink.done(p)
+
+        # step 1: every slot but one written; that one must come out as zero
+        r.begin_step()
+        for i, p in enumerate(params[:-1]):
+            write(p, float((rank + 1) * (i + 1)), False)
+        params[-1]._zk_grad.fill_(123.0)                    # stale data from an earlier step
+        r.finish_backward()
+        for i, p in enumerate(params[:-1]):
+            assert torch.all(p._zk_grad.float() == 3.0 * (i + 1)), (i, p._zk_grad)
+        assert torch.all(params[-1]._zk_grad == 0)
+        assert abs(r.grad_scale - 0.5) < 1e-12
+
+        # step 2: accumulation over two micro-batches, exchange only on the second
+        r.begin_step()
+        with r.no_sync():
+            for p in params:
+                write(p, float(rank + 1), True)
+            r.finish_backward()
+        for p in params:
+            assert torch.all(p._zk_grad.float() == float(rank + 1))      # not exchanged yet
+        for p in params:
+            write(p, float(rank + 1), True)
+        r.finish_backward()
+        for p in params:
+            assert torch.all(p._zk_grad.float() == 6.0)                   # (1+1) + (2+2)
+        r.close()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_two_rank_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
