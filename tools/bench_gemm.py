@@ -32,10 +32,11 @@ def main():
         b = torch.randn((k, n) if tb else (n, k), device="cuda").to(torch.bfloat16)
         out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
         line = f"{name}  M={m:6d} N={n:6d} K={k:6d} :"
-        for cfg, stg in ((0, 10), (0, 11), (1, 11), (2, 10), (2, 11), (3, 11), (-1, 11)):
-            if stg == 10 and not (ta or tb):
+        for cfg, stg in ((0, 11), (1, 11), (1, 20), (2, 11), (3, 11), (-1, 11)):
+            if stg == 20 and (ta or tb):
                 continue
-            ops.set_gemm_tile(stg)
+            ops.set_gemm_tile(21)
+            ops.set_gemm_tile(stg)          # 20 = ring kernel off
             ops.set_gemm_tile(cfg)
             for _ in range(3):
                 ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out)
@@ -47,7 +48,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / iters
-            line += f"  t{cfg:2d}{'d' if stg == 10 else 'r'}: {2.0 * m * n * k / ms / 1e9:7.1f} TF ({ms * 1e3:6.0f} us)"
+            line += f"  t{cfg:2d}{'x' if stg == 20 else 'r'}: {2.0 * m * n * k / ms / 1e9:7.1f} TF ({ms * 1e3:6.0f} us)"
         ops.set_gemm_tile(101)
         for _ in range(3):
             ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out)
@@ -63,6 +64,7 @@ def main():
         print(line, flush=True)
     ops.set_gemm_tile(-1)
     ops.set_gemm_tile(11)
+    ops.set_gemm_tile(21)
 
 
 if __name__ == "__main__":

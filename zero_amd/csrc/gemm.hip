@@ -26,6 +26,7 @@
 // [k][BM|BN] images read with ds_read_b64_tr_b16 (CDNA4 transposed LDS read), so dgrad/wgrad
 // need no transposed copies in HBM.  The MFMA is issued with swapped operands (D = B_frag x
 // A_frag) so each lane ends up with 4 consecutive n of one m: 8-byte C stores.
+#include <type_traits>
 #include "common.h"
 #include "../../include/zero_hip.h"
 
@@ -50,6 +51,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int splits, kchunk;      // split-K: block (tile, s) covers k in [s*kchunk, min(K, (s+1)*kchunk))
   float* slab;             // [splits][M][N] fp32 partial results (split-K only)
+  int pf;                  // ring256: L2 prefetch distance in K-tiles beyond the DMA front (0 = off)
 };
 
 __device__ __forceinline__ int swz_t(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
@@ -145,6 +147,94 @@ __device__ __forceinline__ bf16x8 frag_load(const unsigned char* lds, int mn_bas
   }
 }
 
+// Epilogue.  The MFMA leaves lane l with C[m = l&15][n = 4*(l>>4) .. +3] of each 16x16 fragment:
+// stored from there a wave-instruction touches 16 rows x 32 bytes, and the write-back of a 256x256
+// tile took ~25 us (measured: 0.8-2.3 TB/s chip-wide, a third of the kernel at K = 3072).  So each
+// wave transposes its accumulators through a private LDS patch (32 rows x TN*16 fp32, padded): a
+// lane then owns 8 consecutive n of one row, a wave-instruction writes whole 128-byte rows, and
+// bias / residual / aux operands are read 16 bytes per lane.  `wl` = this wave's patch
+// (kEpiPatchBytes, only used after the block's last operand read; the caller has synchronised).
+constexpr int kEpiPatchBytes = 32 * (4 * 16 + 4) * 4;
+
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile(const GemmArgs& g, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                           int lane, int split, float* wl) {
+  static_assert(TM % 2 == 0 && TN <= 4, "patch is 32 rows x up to 64 columns");
+  constexpr int COLS = TN * 16, LD = COLS + 4, CPRW = COLS / 8, RPP = 64 / CPRW, NPASS = (32 + RPP - 1) / RPP;
+  const int rrow = lane / CPRW, rch = lane % CPRW;
+  const bool lane_on = lane < RPP * CPRW;
+  const int n = n0 + wn * COLS + rch * 8;
+  const bool n_ok = lane_on && n < g.N;
+  float alpha = g.alpha;
+  if (g.alpha_dev) alpha *= *g.alpha_dev;
+  const int epi = g.epilogue;
+  float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (g.bias && n_ok && g.splits == 1) {
+    u32x4 b = *reinterpret_cast<const u32x4*>(g.bias + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bias[2 * e] = lo_bf(b[e]); bias[2 * e + 1] = hi_bf(b[e]); }
+  }
+  float* slab = g.splits > 1 ? g.slab + (size_t)split * g.M * g.N : nullptr;
+#pragma unroll
+  for (int p = 0; p < TM / 2; ++p) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        *reinterpret_cast<f32x4*>(wl + (ii * 16 + (lane & 15)) * LD + j * 16 + (lane >> 4) * 4) = acc[2 * p + ii][j];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int row = ps * RPP + rrow;
+      const int m = m0 + wm * (TM * 16) + p * 32 + row;
+      if (!n_ok || row >= 32 || m >= g.M) continue;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(wl + row * LD + rch * 8);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(wl + row * LD + rch * 8 + 4);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (slab) {   // split-K: fp32 partial sums; splitk_finish_kernel applies alpha / accumulate
+        *reinterpret_cast<f32x4*>(slab + (size_t)m * g.N + n) = lo;
+        *reinterpret_cast<f32x4*>(slab + (size_t)m * g.N + n + 4) = hi;
+        continue;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha + bias[e];
+      if (epi == ZK_EPI_QUICK_GELU || epi == ZK_EPI_GELU_ERF) {
+        // the reference rounds the pre-activation to bf16 before the activation
+        u32x4 pre;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pre[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+        if (g.aux_out) *reinterpret_cast<u32x4*>(g.aux_out + (size_t)m * g.ldc + n) = pre;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = lo_bf(pre[e]); v[2 * e + 1] = hi_bf(pre[e]); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (epi == ZK_EPI_QUICK_GELU) ? act_quick_gelu(v[e]) : act_gelu_erf(v[e]);
+      } else if (epi == ZK_EPI_MUL_DQUICK_GELU || epi == ZK_EPI_MUL_DGELU_ERF) {
+        const u32x4 h = *reinterpret_cast<const u32x4*>(g.aux_in + (size_t)m * g.ldaux + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = (e & 1) ? hi_bf(h[e >> 1]) : lo_bf(h[e >> 1]);
+          v[e] *= (epi == ZK_EPI_MUL_DQUICK_GELU) ? dact_quick_gelu(x) : dact_gelu_erf(x);
+        }
+      }
+      if (g.residual) {
+        // x = residual + bf16(f(x)) : the branch output is rounded before the add
+        const u32x4 r = *reinterpret_cast<const u32x4*>(g.residual + (size_t)m * g.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e])) + ((e & 1) ? hi_bf(r[e >> 1]) : lo_bf(r[e >> 1]));
+      }
+      bf16_t* cp = g.C + (size_t)m * g.ldc + n;
+      if (g.accumulate) {
+        const u32x4 o = *reinterpret_cast<const u32x4*>(cp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (e & 1) ? hi_bf(o[e >> 1]) : lo_bf(o[e >> 1]);
+      }
+      u32x4 out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+      *reinterpret_cast<u32x4*>(cp) = out;
+    }
+  }
+}
+
 template <bool TA, bool TB, int BM, int BN, int WAVES_M, int WAVES_N, int STG>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(GemmArgs g) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -233,74 +323,239 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(GemmArgs g
     __syncthreads();
   }
 
-  // ---- split-K: plain 16-byte fp32 stores into this split's slab; zk_splitk_finish sums the slabs
-  if (g.splits > 1) {
-    float* slab = g.slab + (size_t)split * g.M * g.N;
+  // (the loop's last barrier has passed: no wave reads operand tiles any more)
+  store_tile<TM, TN>(g, acc, m0, n0, wm, wn, lane, split, reinterpret_cast<float*>(smem + wave * kEpiPatchBytes));
+}
+
+// ------------------------------------------------------------------------------------------
+// NT ring variant: NSTAGE LDS stages, the DMA of K-tile t+2 is issued before the MFMAs of tile t
+// and only tile t+1 is waited for (counted s_waitcnt vmcnt, raw s_barrier), so two tiles of HBM/L2
+// latency are covered instead of one.  All LDS in ONE array (no compiler-inserted vmcnt(0)).
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int MODE = 0>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_ring_kernel(GemmArgs g) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
+  constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = (BM + BN) * BK * 2;
+  constexpr int PER = (BM + BN) * 8 / NT;      // DMA instructions per thread per K-tile
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int split = blockIdx.x / nwg;
+  int bid = blockIdx.x - split * nwg;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int band = bid / (8 * g.tiles_n);
+  const int band_m = min(8, g.tiles_m - band * 8);
+  const int within = bid - band * 8 * g.tiles_n;
+  const int tm = band * 8 + within % band_m;
+  const int tn = within / band_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  __amdgpu_buffer_rsrc_t rA = make_rsrc(g.A + (size_t)m0 * g.lda, 0x7FFFFFF0u);
+  __amdgpu_buffer_rsrc_t rB = make_rsrc(g.B + (size_t)n0 * g.ldb, 0x7FFFFFF0u);
+
+  f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m = m0 + wm * (TM * 16) + i * 16 + (lane & 15);
-      if (m >= g.M) continue;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (TN * 16) + j * 16 + (lane >> 4) * 4;
-        if (n >= g.N) continue;
-        *reinterpret_cast<f32x4*>(slab + (size_t)m * g.N + n) = acc[i][j];
-      }
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kb = split * g.kchunk;
+  const int Ke = min(g.K, kb + g.kchunk);
+  const int nk = (Ke - kb + BK - 1) / BK;
+  auto issue = [&](int t) {
+    unsigned char* st = smem + (t % NSTAGE) * STAGE_BYTES;
+    tile_dma<false, BM, NT>(rA, st, g.lda, m0, g.M, kb + t * BK, Ke, tid);
+    tile_dma<false, BN, NT>(rB, st + A_BYTES, g.ldb, n0, g.N, kb + t * BK, Ke, tid);
+  };
+  issue(0);
+  if (nk > 1) {
+    issue(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+
+  // Fragment double buffering: the ds_reads of the NEXT k-half are issued before the MFMAs of the
+  // current one, so LDS latency hides behind 16 MFMAs of the same wave.
+  bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  auto load_frags = [&](bf16x8 (&fa)[TM], bf16x8 (&fb)[TN], int t, int kk) {
+    const unsigned char* la = smem + (t % NSTAGE) * STAGE_BYTES;
+    const unsigned char* lb = la + A_BYTES;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = frag_load<false, BN>(lb, wn * (TN * 16) + j * 16, kk, lane);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = frag_load<false, BM>(la, wm * (TM * 16) + i * 16, kk, lane);
+  };
+  auto mfma_all = [&](bf16x8 (&fa)[TM], bf16x8 (&fb)[TN]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  load_frags(fa0, fb0, 0, 0);
+  for (int t = 0; t < nk; ++t) {
+    if (MODE != 2 && t + 2 < nk) issue(t + 2);
+    if (MODE != 1) {
+      load_frags(fa1, fb1, t, 1);
+      mfma_all(fa0, fb0);
     }
+    if (t + 1 < nk) {
+      // tile t+1 (issued one iteration ago) must have landed; tile t+2 stays in flight
+      if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (MODE != 1) load_frags(fa0, fb0, t + 1, 0);
+    }
+    if (MODE != 1) mfma_all(fa1, fb1);
+  }
+  __syncthreads();   // every wave has its last fragments in registers: LDS becomes epilogue scratch
+  store_tile<TM, TN>(g, acc, m0, n0, wm, wn, lane, split, reinterpret_cast<float*>(smem + wave * kEpiPatchBytes));
+}
+
+// ------------------------------------------------------------------------------------------
+// NT 256x256 ring: measured on MI355X, LDS-DMA from L2 tops out near 55-70 GB/s per CU, so the
+// operand bytes per flop (not the MFMA rate) bound the 128x128 and 256x128 tiles near 1.0-1.2 PF.
+// A 256x256 tile needs 7.8 B/kflop (256x128: 11.7, 128x128: 15.6).  Its 64 KiB K-tiles do not fit
+// three times in 160 KiB of LDS, so the ring is cut in HALF-tiles: five 32 KiB slots hold
+// A_t B_t A_t+1 B_t+1 A_t+2; when tile t is consumed its two slots take B_t+2 and A_t+3.  One
+// barrier per K-tile, 64-96 KiB of DMA always queued.  8 waves, 128x64 of C per wave; fragments
+// are double-buffered across the two k-halves so ds_read latency hides behind 32 MFMAs.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(512) void gemm_ring256_kernel(GemmArgs g) {
+  constexpr int BM = 256, BN = 256, WAVES_N = 4, NT = 512;
+  constexpr int TM = 8, TN = 4;
+  constexpr int SLOT = 256 * BK * 2, NSLOT = 5;
+  constexpr int PERH = 256 * 8 / NT;            // DMA instructions per thread per half-tile
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * SLOT];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int nwg = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int band = bid / (8 * g.tiles_n);
+  const int band_m = min(8, g.tiles_m - band * 8);
+  const int within = bid - band * 8 * g.tiles_n;
+  const int tm = band * 8 + within % band_m;
+  const int tn = within / band_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  __amdgpu_buffer_rsrc_t rA = make_rsrc(g.A + (size_t)m0 * g.lda, 0x7FFFFFF0u);
+  __amdgpu_buffer_rsrc_t rB = make_rsrc(g.B + (size_t)n0 * g.ldb, 0x7FFFFFF0u);
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (g.K + BK - 1) / BK;
+  auto issue_a = [&](int t) { tile_dma<false, BM, NT>(rA, smem + ((2 * t) % NSLOT) * SLOT, g.lda, m0, g.M, t * BK, g.K, tid); };
+  auto issue_b = [&](int t) { tile_dma<false, BN, NT>(rB, smem + ((2 * t + 1) % NSLOT) * SLOT, g.ldb, n0, g.N, t * BK, g.K, tid); };
+  issue_a(0);
+  issue_b(0);
+  if (nk > 1) { issue_a(1); issue_b(1); }
+  if (nk > 2) issue_a(2);
+  // L2 prefetch: one dword per 128-byte line of K-tile t (thread r < 256: A row r, else B row r - 256).
+  // The value is never used; the register stays pinned ("+v") so the late write-back is harmless.
+  const int pf = g.pf;
+  unsigned int pf_sink = 0;
+  const bf16_t* pf_row;
+  {
+    const int r = tid & 255;
+    pf_row = tid < 256 ? g.A + (size_t)min(m0 + r, g.M - 1) * g.lda : g.B + (size_t)min(n0 + r, g.N - 1) * g.ldb;
+  }
+  auto prefetch = [&](int t) {
+    const bf16_t* p = pf_row + (size_t)t * BK;
+    asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(p) : "memory");
+  };
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PERH) : "memory");
+  else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PERH) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  auto load_frags = [&](bf16x8 (&fa)[TM], bf16x8 (&fb)[TN], int t, int kk) {
+    const unsigned char* la = smem + ((2 * t) % NSLOT) * SLOT;
+    const unsigned char* lb = smem + ((2 * t + 1) % NSLOT) * SLOT;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = frag_load<false, BN>(lb, wn * (TN * 16) + j * 16, kk, lane);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = frag_load<false, BM>(la, wm * (TM * 16) + i * 16, kk, lane);
+  };
+  auto mfma_all = [&](bf16x8 (&fa)[TM], bf16x8 (&fb)[TN]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // One K-tile.  The three flags are compile-time so the steady-state loop body is straight-line
+  // code: with the tail cases merged in, the compiler's s_waitcnt placement has to assume the
+  // shortest LDS queue and ends up waiting for the just-issued reads before the second MFMA burst.
+  auto step = [&](int t, auto has_next, auto do_b, auto do_a) {
+    if (MODE != 1) {
+      load_frags(fa1, fb1, t, 1);
+      mfma_all(fa0, fb0);
+    }
+    if constexpr (decltype(has_next)::value) {
+      // tile t+1 must have landed (A_t+2, and one prefetch load issued after it, may stay in
+      // flight) and every wave must have its fragments of tile t in registers before the two
+      // slots are refilled
+      if constexpr (decltype(do_b)::value) {
+        if (pf) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PERH + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PERH) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (MODE != 2) {
+        if constexpr (decltype(do_b)::value) issue_b(t + 2);
+        if constexpr (decltype(do_a)::value) {
+          issue_a(t + 3);
+          if (pf && t + 3 + pf < nk) prefetch(t + 3 + pf);
+        }
+      }
+      if (MODE != 1) load_frags(fa0, fb0, t + 1, 0);
+    }
+    if (MODE != 1) mfma_all(fa1, fb1);
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  if (MODE != 1) load_frags(fa0, fb0, 0, 0);
+  int t = 0;
+  for (; t + 3 < nk; ++t) step(t, T_{}, T_{}, T_{});
+  if (t + 2 < nk) { step(t, T_{}, T_{}, F_{}); ++t; }
+  if (t + 1 < nk) { step(t, T_{}, F_{}, F_{}); ++t; }
+  step(t, F_{}, F_{}, F_{});
+  if (pf_sink == 0x7FC12345u && nk < 0) acc[0][0][0] = 1.f;   // keeps pf_sink's register live to here
+  if (MODE == 3) {   // experiment: no epilogue (one conditional store keeps the accumulators alive)
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum == 123.456f) g.C[0] = f2bf(sum);
     return;
   }
-  // ---- epilogue: lane holds C[m][n..n+3], m = l&15, n = 4*(l>>4) + reg ----
-  float alpha = g.alpha;
-  if (g.alpha_dev) alpha *= *g.alpha_dev;
-  const int epi = g.epilogue;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * (TM * 16) + i * 16 + (lane & 15);
-    if (m >= g.M) continue;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (TN * 16) + j * 16 + (lane >> 4) * 4;
-      if (n >= g.N) continue;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * alpha;
-      if (g.bias) {
-        u32x2 b = *reinterpret_cast<const u32x2*>(g.bias + n);
-        v[0] += lo_bf(b[0]); v[1] += hi_bf(b[0]); v[2] += lo_bf(b[1]); v[3] += hi_bf(b[1]);
-      }
-      if (epi == ZK_EPI_QUICK_GELU || epi == ZK_EPI_GELU_ERF) {
-        // the reference rounds the pre-activation to bf16 before the activation
-        u32x2 pre;
-        pre[0] = pack2bf(v[0], v[1]);
-        pre[1] = pack2bf(v[2], v[3]);
-        if (g.aux_out) *reinterpret_cast<u32x2*>(g.aux_out + (size_t)m * g.ldc + n) = pre;
-        v[0] = lo_bf(pre[0]); v[1] = hi_bf(pre[0]); v[2] = lo_bf(pre[1]); v[3] = hi_bf(pre[1]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (epi == ZK_EPI_QUICK_GELU) ? act_quick_gelu(v[e]) : act_gelu_erf(v[e]);
-      } else if (epi == ZK_EPI_MUL_DQUICK_GELU || epi == ZK_EPI_MUL_DGELU_ERF) {
-        u32x2 h = *reinterpret_cast<const u32x2*>(g.aux_in + (size_t)m * g.ldaux + n);
-        float x[4] = {lo_bf(h[0]), hi_bf(h[0]), lo_bf(h[1]), hi_bf(h[1])};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          v[e] *= (epi == ZK_EPI_MUL_DQUICK_GELU) ? dact_quick_gelu(x[e]) : dact_gelu_erf(x[e]);
-      }
-      if (g.residual) {
-        // x = residual + bf16(f(x)) : the branch output is rounded before the add
-        u32x2 r = *reinterpret_cast<const u32x2*>(g.residual + (size_t)m * g.ldr + n);
-        v[0] = bf2f(f2bf(v[0])) + lo_bf(r[0]); v[1] = bf2f(f2bf(v[1])) + hi_bf(r[0]);
-        v[2] = bf2f(f2bf(v[2])) + lo_bf(r[1]); v[3] = bf2f(f2bf(v[3])) + hi_bf(r[1]);
-      }
-      bf16_t* cp = g.C + (size_t)m * g.ldc + n;
-      if (g.accumulate) {
-        u32x2 o = *reinterpret_cast<const u32x2*>(cp);
-        v[0] += lo_bf(o[0]); v[1] += hi_bf(o[0]); v[2] += lo_bf(o[1]); v[3] += hi_bf(o[1]);
-      }
-      u32x2 out;
-      out[0] = pack2bf(v[0], v[1]);
-      out[1] = pack2bf(v[2], v[3]);
-      *reinterpret_cast<u32x2*>(cp) = out;
-    }
-  }
+  __syncthreads();   // every wave has its last fragments in registers: LDS becomes epilogue scratch
+  store_tile<TM, TN>(g, acc, m0, n0, wm, wn, lane, 0, reinterpret_cast<float*>(smem + wave * kEpiPatchBytes));
 }
 
 // C = bf16(alpha * sum_s slab[s] (+ C)), 4 columns per thread
@@ -335,6 +590,9 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* slab, b
 namespace {
 int g_force_tile = -1;   // tuning hook: -1 = cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256
 int g_force_splits = 0;  // tuning hook: 0 = heuristic, 1 = never split K, n > 1 = force n splits
+int g_pf = 0;            // experiment hook: ring256 L2 prefetch distance
+int g_ring_mode = 0;     // experiment hook: 1 = ring kernel without MFMAs, 2 = without DMA (wrong results)
+int g_ring = 1;          // tuning hook: 1 = 3-stage ring kernel for NT products on the 256x128 tile
 int g_stage_mode = 1;    // tuning hook: 0 = LDS-DMA for every operand, 1 = registers for transposed operands
 
 template <int BM, int BN, int WM_, int WN_>
@@ -355,11 +613,12 @@ void launch_cfg(const GemmArgs& g0, int transA, int transB, hipStream_t stream) 
 }
 
 // Tile choice: time ~ rounds(tiles / concurrent blocks) x tile area / relative efficiency.
-int choose_tile(int64_t M, int64_t N, int transB) {
+int choose_tile(int64_t M, int64_t N, int transA, int transB) {
   if (g_force_tile >= 0) return (g_force_tile == 3 && transB) ? 0 : g_force_tile;
   const int bm[4] = {128, 256, 256, 128}, bn[4] = {128, 128, 256, 96};
   const double slots[4] = {512.0, 256.0, 256.0, 512.0};   // two 4-wave blocks or one 8-wave block per CU
-  const double eff[4] = {1.0, 0.85, 1.02, 0.93};          // measured on MI355X (tools/bench_gemm.py)
+  // measured on MI355X (tools/bench_gemm.py); the 256x256 half-tile ring exists for NT products only
+  const double eff[4] = {1.0, 0.9, (!transA && !transB && g_ring) ? 1.2 : 1.02, 0.93};
   int best = 0;
   double best_cost = 1e300;
   for (int c = 0; c < (transB ? 3 : 4); ++c) {
@@ -375,6 +634,9 @@ int choose_tile(int64_t M, int64_t N, int transB) {
 extern "C" int zk_gemm_set_tile(int cfg) {
   // cfg in [-1, 2] selects the tile; cfg = 10 / 11 selects the staging mode (0 / 1)
   if (cfg == 10 || cfg == 11) { g_stage_mode = cfg - 10; return ZK_OK; }
+  if (cfg == 20 || cfg == 21) { g_ring = cfg - 20; return ZK_OK; }
+  if (cfg >= 30 && cfg <= 33) { g_ring_mode = cfg - 30; return ZK_OK; }
+  if (cfg >= 40 && cfg <= 56) { g_pf = cfg - 40; return ZK_OK; }
   if (cfg >= 100 && cfg <= 116) { g_force_splits = cfg - 100; return ZK_OK; }   // 100 = heuristic, 101 = off
   if (cfg < -1 || cfg > 3) return ZK_EINVAL;
   g_force_tile = cfg;
@@ -387,15 +649,18 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
                             float alpha, const float* alpha_dev, int accumulate, void* workspace,
                             int64_t workspace_bytes, hipStream_t stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ZK_EINVAL;
-  if ((N & 7) || (ldc & 3)) return ZK_EINVAL;
+  if ((N & 7) || (ldc & 7)) return ZK_EINVAL;   // the epilogue moves 8 consecutive n (16 bytes) per lane
   if ((!transA || !transB) && (K & 7)) return ZK_EINVAL;  // k-contiguous operands are read in 8-element chunks
   if (transA ? ((M & 7) || (lda & 7)) : (lda & 7)) return ZK_EINVAL;
   if (ldb & 7) return ZK_EINVAL;
   if (epilogue < 0 || epilogue > ZK_EPI_MUL_DGELU_ERF) return ZK_EINVAL;
   if ((epilogue == ZK_EPI_MUL_DQUICK_GELU || epilogue == ZK_EPI_MUL_DGELU_ERF) && !aux_in) return ZK_EINVAL;
-  if (residual && (ldr & 3)) return ZK_EINVAL;
+  if (residual && ((ldr & 7) || (reinterpret_cast<uintptr_t>(residual) & 15))) return ZK_EINVAL;
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) return ZK_EINVAL;
+  if (aux_in && ((ldaux & 7) || (reinterpret_cast<uintptr_t>(aux_in) & 15))) return ZK_EINVAL;
+  if (aux_out && (reinterpret_cast<uintptr_t>(aux_out) & 15)) return ZK_EINVAL;
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) return ZK_EINVAL;
-  if (reinterpret_cast<uintptr_t>(C) & 7) return ZK_EINVAL;
+  if (reinterpret_cast<uintptr_t>(C) & 15) return ZK_EINVAL;
   // 32-bit byte offsets inside one block tile
   if ((transA ? K : 256) * lda * 2 >= 0x7FFFFFF0LL || (transB ? K : 256) * ldb * 2 >= 0x7FFFFFF0LL) return ZK_EINVAL;
   GemmArgs g;
@@ -408,6 +673,7 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
   g.epilogue = epilogue; g.accumulate = accumulate;
   g.tiles_m = g.tiles_n = 0;
   g.splits = 1; g.kchunk = (int)((K + BK - 1) / BK * BK); g.slab = nullptr;
+  g.pf = g_pf;
   // split-K for small outputs with a long contraction (wgrad, lm_head dgrad): fill the 256 CUs
   const bool plain = epilogue == ZK_EPI_NONE && !bias && !residual && !aux_out;
   if (plain && workspace && g_force_splits != 1) {
@@ -431,10 +697,33 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
     ZK_CHECK_LAUNCH();
     return ZK_OK;
   }
-  switch (choose_tile(M, N, transB)) {
+  switch (choose_tile(M, N, transA, transB)) {
     case 3: launch_cfg<128, 96, 2, 2>(g, transA, transB, stream); break;
-    case 2: launch_cfg<256, 256, 2, 4>(g, transA, transB, stream); break;
-    case 1: launch_cfg<256, 128, 4, 2>(g, transA, transB, stream); break;
+    case 2:
+      if (!transA && !transB && g_ring) {
+        GemmArgs gr = g;
+        gr.tiles_m = (g.M + 255) / 256; gr.tiles_n = (g.N + 255) / 256;
+        const dim3 rg(gr.tiles_m * gr.tiles_n);
+        if (g_ring_mode == 1) hipLaunchKernelGGL((gemm_ring256_kernel<1>), rg, dim3(512), 0, stream, gr);
+        else if (g_ring_mode == 2) hipLaunchKernelGGL((gemm_ring256_kernel<2>), rg, dim3(512), 0, stream, gr);
+        else if (g_ring_mode == 3) hipLaunchKernelGGL((gemm_ring256_kernel<3>), rg, dim3(512), 0, stream, gr);
+        else hipLaunchKernelGGL((gemm_ring256_kernel<0>), rg, dim3(512), 0, stream, gr);
+      } else {
+        launch_cfg<256, 256, 2, 4>(g, transA, transB, stream);
+      }
+      break;
+    case 1:
+      if (!transA && !transB && g_ring) {
+        GemmArgs gr = g;
+        gr.tiles_m = (g.M + 255) / 256; gr.tiles_n = (g.N + 127) / 128;
+        const dim3 rg(gr.tiles_m * gr.tiles_n);
+        if (g_ring_mode == 1) hipLaunchKernelGGL((gemm_ring_kernel<256, 128, 4, 2, 3, 1>), rg, dim3(512), 0, stream, gr);
+        else if (g_ring_mode == 2) hipLaunchKernelGGL((gemm_ring_kernel<256, 128, 4, 2, 3, 2>), rg, dim3(512), 0, stream, gr);
+        else hipLaunchKernelGGL((gemm_ring_kernel<256, 128, 4, 2, 3>), rg, dim3(512), 0, stream, gr);
+      } else {
+        launch_cfg<256, 128, 4, 2>(g, transA, transB, stream);
+      }
+      break;
     default: launch_cfg<128, 128, 2, 2>(g, transA, transB, stream); break;
   }
   ZK_CHECK_LAUNCH();
