@@ -26,7 +26,7 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.fixture(params=[-1, 0, 1, 2, 3], ids=["auto", "t128", "t256x128", "t256", "t128x96"])
+@pytest.fixture(params=[-1, 0, 1, 2, 3, 4], ids=["auto", "t128", "t256x128", "t256", "t128x96", "t384x192"])
 def gemm_tile(request):
     """Every GEMM test runs under the cost model and under each forced block tile."""
     ops.set_gemm_tile(request.param)
@@ -34,7 +34,8 @@ def gemm_tile(request):
     ops.set_gemm_tile(-1)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (577 * 3, 1024, 640), (130, 72, 40), (64, 3072, 1024)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (577 * 3, 1024, 640), (130, 72, 40), (64, 3072, 1024),
+                                   (800, 400, 128), (1000, 776, 264), (390, 200, 328)])
 def test_gemm_nt(M, N, K, gemm_tile):
     a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
     c = ops.gemm(a, b)

@@ -11,6 +11,9 @@ SHAPES = [  # (name, M, N, K, trans_a, trans_b)
     ("dec o      NT", M, 3072, 3072, False, False),
     ("dec gateup NT", M, 16384, 3072, False, False),
     ("dec down   NT", M, 3072, 8192, False, False),
+    ("dec d_down NT", M, 8192, 3072, False, False),
+    ("dec d_gu   NT", M, 3072, 16384, False, False),
+    ("dec d_qkv  NT", M, 3072, 5120, False, False),
     ("dec d_down NN", M, 8192, 3072, False, True),
     ("dec d_gu   NN", M, 3072, 16384, False, True),
     ("dec d_qkv  NN", M, 3072, 5120, False, True),
@@ -32,11 +35,11 @@ def main():
         b = torch.randn((k, n) if tb else (n, k), device="cuda").to(torch.bfloat16)
         out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
         line = f"{name}  M={m:6d} N={n:6d} K={k:6d} :"
-        for cfg, stg in ((0, 11), (1, 11), (1, 20), (2, 11), (3, 11), (-1, 11)):
-            if stg == 20 and (ta or tb):
+        for cfg, stg in ((0, 11), (1, 11), (2, 11), (3, 11), (4, 11), (-1, 11)):
+            if (stg == 22 or cfg == 4) and (ta or tb):
                 continue
             ops.set_gemm_tile(21)
-            ops.set_gemm_tile(stg)          # 20 = ring kernel off
+            ops.set_gemm_tile(stg)          # 22 = older 256x256 ring kernel
             ops.set_gemm_tile(cfg)
             for _ in range(3):
                 ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out)
@@ -48,7 +51,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / iters
-            line += f"  t{cfg:2d}{'x' if stg == 20 else 'r'}: {2.0 * m * n * k / ms / 1e9:7.1f} TF ({ms * 1e3:6.0f} us)"
+            line += f"  t{cfg:2d}{'o' if stg == 22 else 'r'}: {2.0 * m * n * k / ms / 1e9:7.1f} TF ({ms * 1e3:6.0f} us)"
         ops.set_gemm_tile(101)
         for _ in range(3):
             ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out)

@@ -51,7 +51,6 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int splits, kchunk;      // split-K: block (tile, s) covers k in [s*kchunk, min(K, (s+1)*kchunk))
   float* slab;             // [splits][M][N] fp32 partial results (split-K only)
-  int pf;                  // ring256: L2 prefetch distance in K-tiles beyond the DMA front (0 = off)
 };
 
 __device__ __forceinline__ int swz_t(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
@@ -74,7 +73,7 @@ __device__ __forceinline__ float dact_gelu_erf(float x) {
 //    T : image [64k][R],  R/8 slots per k-row; slot (k, pos) holds mn-chunk  pos ^ swz_t(k)
 template <bool T, int R, int NT>
 __device__ __forceinline__ void tile_dma(__amdgpu_buffer_rsrc_t rs, unsigned char* lds, int ld, int mn0, int MN, int k0,
-                                         int K, int tid) {
+                                         int K, int tid, int row0 = 0) {
   constexpr int N = R * 8 / NT;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -83,8 +82,8 @@ __device__ __forceinline__ void tile_dma(__amdgpu_buffer_rsrc_t rs, unsigned cha
     bool ok;
     if (!T) {
       const int row = s >> 3, kc = (s & 7) ^ (row & 7);
-      ok = (mn0 + row < MN) && (k0 + kc * 8 < K);
-      off = (unsigned int)(row * ld + k0 + kc * 8) * 2u;
+      ok = (mn0 + row0 + row < MN) && (k0 + kc * 8 < K);
+      off = (unsigned int)((row0 + row) * ld + k0 + kc * 8) * 2u;
     } else {
       constexpr int CPR = R / 8;
       const int kr = s / CPR, ch = (s % CPR) ^ swz_t(kr);
@@ -423,20 +422,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_ring_kernel(GemmA
 }
 
 // ------------------------------------------------------------------------------------------
-// NT 256x256 ring: measured on MI355X, LDS-DMA from L2 tops out near 55-70 GB/s per CU, so the
-// operand bytes per flop (not the MFMA rate) bound the 128x128 and 256x128 tiles near 1.0-1.2 PF.
-// A 256x256 tile needs 7.8 B/kflop (256x128: 11.7, 128x128: 15.6).  Its 64 KiB K-tiles do not fit
-// three times in 160 KiB of LDS, so the ring is cut in HALF-tiles: five 32 KiB slots hold
-// A_t B_t A_t+1 B_t+1 A_t+2; when tile t is consumed its two slots take B_t+2 and A_t+3.  One
-// barrier per K-tile, 64-96 KiB of DMA always queued.  8 waves, 128x64 of C per wave; fragments
-// are double-buffered across the two k-halves so ds_read latency hides behind 32 MFMAs.
+// NT slot ring, the kernel for the large products.  Measured on MI355X, LDS-DMA from L2 tops out
+// near 55-70 GB/s per CU, so operand bytes per flop (not the MFMA rate) bound the 128x128 and
+// 256x128 tiles near 1.0-1.2 PF: a 256x256 tile needs 7.8 B/kflop (256x128: 11.7, 128x128: 15.6).
+// Its 64 KiB K-tiles do not fit three times in 160 KiB of LDS, so the ring is cut in SLOTS of RS
+// rows x 64 k: BM/RS slots of A then BN/RS slots of B per K-tile, NSLOT slots in LDS.
+//   256x256 -> RS 256, 5 slots: A_t B_t A_t+1 B_t+1 A_t+2; when tile t is consumed its two slots
+//              take B_t+2 and A_t+3: one barrier per K-tile, 64-96 KiB of DMA always queued.
+//   384x192 -> RS 192, 6 slots: M = 6144, N = 3072 is exactly 256 such tiles, one per CU, at the
+//              same 7.8 B/kflop (288 tiles of 256x256 would run a second, 12 %-full round).
+// 8 waves.  Registers: accumulators + A fragments refilled right after the last MFMA that reads
+// each (rolling), B fragments double-buffered: ds_read latency hides behind the MFMAs.  The
+// steady-state K loop is straight-line code (tail steps are separate instantiations): with the
+// tail cases merged in, the compiler's s_waitcnt placement assumes the shortest LDS queue and
+// waits for just-issued reads.  MODE 1/2/3 are ablations (no MFMA / no DMA / no epilogue).
 // ------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(512) void gemm_ring256_kernel(GemmArgs g) {
-  constexpr int BM = 256, BN = 256, WAVES_N = 4, NT = 512;
-  constexpr int TM = 8, TN = 4;
-  constexpr int SLOT = 256 * BK * 2, NSLOT = 5;
-  constexpr int PERH = 256 * 8 / NT;            // DMA instructions per thread per half-tile
+template <int BM, int BN, int WAVES_M, int WAVES_N, int RS, int NSLOT, int MODE>
+__global__ __launch_bounds__(512) void gemm_ringx_kernel(GemmArgs g) {
+  constexpr int NT = 512;
+  static_assert(WAVES_M * WAVES_N == 8, "8 waves");
+  constexpr int TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
+  constexpr int SA = BM / RS, SB = BN / RS, SPT = SA + SB;
+  static_assert(SA * RS == BM && SB * RS == BN && NSLOT >= 2 * SPT && NSLOT - 2 * SPT <= SPT, "slot geometry");
+  static_assert((TM * 16) <= RS && RS % (TM * 16) == 0 && RS % (TN * 16) == 0, "a wave's rows lie in one slot");
+  constexpr int SLOT = RS * BK * 2;
+  constexpr int PER = RS * 8 / NT;             // DMA instructions per thread per slot
+  static_assert(PER * NT == RS * 8, "slot rows");
+  constexpr int AHEAD = NSLOT - 2 * SPT;       // slots that may stay in flight when tile t+1 is needed
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * SLOT];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -464,87 +476,94 @@ __global__ __launch_bounds__(512) void gemm_ring256_kernel(GemmArgs g) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (g.K + BK - 1) / BK;
-  auto issue_a = [&](int t) { tile_dma<false, BM, NT>(rA, smem + ((2 * t) % NSLOT) * SLOT, g.lda, m0, g.M, t * BK, g.K, tid); };
-  auto issue_b = [&](int t) { tile_dma<false, BN, NT>(rB, smem + ((2 * t + 1) % NSLOT) * SLOT, g.ldb, n0, g.N, t * BK, g.K, tid); };
-  issue_a(0);
-  issue_b(0);
-  if (nk > 1) { issue_a(1); issue_b(1); }
-  if (nk > 2) issue_a(2);
-  // L2 prefetch: one dword per 128-byte line of K-tile t (thread r < 256: A row r, else B row r - 256).
-  // The value is never used; the register stays pinned ("+v") so the late write-back is harmless.
-  const int pf = g.pf;
-  unsigned int pf_sink = 0;
-  const bf16_t* pf_row;
-  {
-    const int r = tid & 255;
-    pf_row = tid < 256 ? g.A + (size_t)min(m0 + r, g.M - 1) * g.lda : g.B + (size_t)min(n0 + r, g.N - 1) * g.ldb;
-  }
-  auto prefetch = [&](int t) {
-    const bf16_t* p = pf_row + (size_t)t * BK;
-    asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(p) : "memory");
+  const int total = nk * SPT;                  // slot loads of the whole K loop, in ring order
+  // slot load q = (K-tile q / SPT, part q % SPT); parts 0..SA-1 are A row blocks, SA.. are B's
+  auto issue = [&](int q) {
+    const int t = q / SPT, part = q - t * SPT;
+    unsigned char* dst = smem + (q % NSLOT) * SLOT;
+    if (part < SA) tile_dma<false, RS, NT>(rA, dst, g.lda, m0, g.M, t * BK, g.K, tid, part * RS);
+    else tile_dma<false, RS, NT>(rB, dst, g.ldb, n0, g.N, t * BK, g.K, tid, (part - SA) * RS);
   };
-  if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PERH) : "memory");
-  else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PERH) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  auto wait_slots = [&](int nslots) {          // at most nslots slot loads may remain in flight
+    switch (nslots) {
+      case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PER) : "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * PER) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * PER) : "memory"); break;
+    }
+  };
+  static_assert(NSLOT - SPT <= 4 && 4 * PER <= 63, "wait_slots covers the prologue");
+  {
+    const int first = min(NSLOT, total);
+    for (int q = 0; q < first; ++q) issue(q);
+    wait_slots(first - SPT);
+  }
   __builtin_amdgcn_s_barrier();
 
-  bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-  auto load_frags = [&](bf16x8 (&fa)[TM], bf16x8 (&fb)[TN], int t, int kk) {
-    const unsigned char* la = smem + ((2 * t) % NSLOT) * SLOT;
-    const unsigned char* lb = smem + ((2 * t + 1) % NSLOT) * SLOT;
+  // LDS addresses of this wave's fragments inside K-tile t
+  const int a_part = wm * (TM * 16) / RS, a_row = wm * (TM * 16) - a_part * RS;
+  const int b_part = SA + wn * (TN * 16) / RS, b_row = wn * (TN * 16) % RS;
+  auto lds_a = [&](int t) { return smem + ((t * SPT + a_part) % NSLOT) * SLOT; };
+  auto lds_b = [&](int t) { return smem + ((t * SPT + b_part) % NSLOT) * SLOT; };
+
+  bf16x8 fa[TM], fb0[TN], fb1[TN];
+  // One k-half: MFMAs on (fa, fcur) while the fragments of the NEXT k-half arrive: B's into the
+  // other buffer up front, each A fragment in place as soon as its last MFMA has been issued.
+  auto burst = [&](bf16x8 (&fcur)[TN], bf16x8 (&fnext)[TN], const unsigned char* na, const unsigned char* nb, int nkk,
+                   auto has_next) {
+    constexpr bool NX = decltype(has_next)::value;
+    if constexpr (NX) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) fb[j] = frag_load<false, BN>(lb, wn * (TN * 16) + j * 16, kk, lane);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fa[i] = frag_load<false, BM>(la, wm * (TM * 16) + i * 16, kk, lane);
-  };
-  auto mfma_all = [&](bf16x8 (&fa)[TM], bf16x8 (&fb)[TN]) {
+      for (int j = 0; j < TN; ++j) fnext[j] = frag_load<false, RS>(nb, b_row + j * 16, nkk, lane);
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fcur[j], fa[i], acc[i][j], 0, 0, 0);
+      // (scheduling fence: keep the refill BEHIND the MFMAs that read the old value, or the
+      //  compiler hoists it into fresh registers and the kernel no longer fits 256 VGPRs)
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NX) fa[i] = frag_load<false, RS>(na, a_row + i * 16, nkk, lane);
+    }
     __builtin_amdgcn_s_setprio(0);
-  };
-  // One K-tile.  The three flags are compile-time so the steady-state loop body is straight-line
-  // code: with the tail cases merged in, the compiler's s_waitcnt placement has to assume the
-  // shortest LDS queue and ends up waiting for the just-issued reads before the second MFMA burst.
-  auto step = [&](int t, auto has_next, auto do_b, auto do_a) {
-    if (MODE != 1) {
-      load_frags(fa1, fb1, t, 1);
-      mfma_all(fa0, fb0);
-    }
-    if constexpr (decltype(has_next)::value) {
-      // tile t+1 must have landed (A_t+2, and one prefetch load issued after it, may stay in
-      // flight) and every wave must have its fragments of tile t in registers before the two
-      // slots are refilled
-      if constexpr (decltype(do_b)::value) {
-        if (pf) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PERH + 1) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PERH) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      if (MODE != 2) {
-        if constexpr (decltype(do_b)::value) issue_b(t + 2);
-        if constexpr (decltype(do_a)::value) {
-          issue_a(t + 3);
-          if (pf && t + 3 + pf < nk) prefetch(t + 3 + pf);
-        }
-      }
-      if (MODE != 1) load_frags(fa0, fb0, t + 1, 0);
-    }
-    if (MODE != 1) mfma_all(fa1, fb1);
   };
   using T_ = std::true_type;
   using F_ = std::false_type;
-  if (MODE != 1) load_frags(fa0, fb0, 0, 0);
+  // One K-tile; STEADY = every refill of this step exists and tile t+2 exists (straight-line code)
+  auto step = [&](int t, auto steady, auto has_next) {
+    constexpr bool ST = decltype(steady)::value, HN = decltype(has_next)::value;
+    if (MODE != 1) burst(fb0, fb1, lds_a(t), lds_b(t), 1, T_{});
+    if constexpr (HN) {
+      // tile t+1 must have landed and every wave must hold its last fragments of tile t before the
+      // slots of tile t are refilled
+      if (ST) wait_slots(AHEAD);
+      else wait_slots(t + 2 < nk ? AHEAD : 0);
+      __builtin_amdgcn_s_barrier();
+      if (MODE != 2) {
+#pragma unroll
+        for (int r = 0; r < SPT; ++r) {
+          const int q = t * SPT + NSLOT + r;
+          if (ST || q < total) issue(q);
+        }
+      }
+      if (MODE != 1) burst(fb1, fb0, lds_a(t + 1), lds_b(t + 1), 0, T_{});
+    } else {
+      if (MODE != 1) burst(fb1, fb0, nullptr, nullptr, 0, F_{});
+    }
+  };
+  if (MODE != 1) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb0[j] = frag_load<false, RS>(lds_b(0), b_row + j * 16, 0, lane);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = frag_load<false, RS>(lds_a(0), a_row + i * 16, 0, lane);
+  }
   int t = 0;
-  for (; t + 3 < nk; ++t) step(t, T_{}, T_{}, T_{});
-  if (t + 2 < nk) { step(t, T_{}, T_{}, F_{}); ++t; }
-  if (t + 1 < nk) { step(t, T_{}, F_{}, F_{}); ++t; }
-  step(t, F_{}, F_{}, F_{});
-  if (pf_sink == 0x7FC12345u && nk < 0) acc[0][0][0] = 1.f;   // keeps pf_sink's register live to here
+  for (; (t + 1) * SPT + NSLOT <= total && t + 2 < nk; ++t) step(t, T_{}, T_{});
+  for (; t + 1 < nk; ++t) step(t, F_{}, T_{});
+  step(t, F_{}, F_{});
   if (MODE == 3) {   // experiment: no epilogue (one conditional store keeps the accumulators alive)
     float sum = 0.f;
 #pragma unroll
@@ -590,7 +609,6 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* slab, b
 namespace {
 int g_force_tile = -1;   // tuning hook: -1 = cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256
 int g_force_splits = 0;  // tuning hook: 0 = heuristic, 1 = never split K, n > 1 = force n splits
-int g_pf = 0;            // experiment hook: ring256 L2 prefetch distance
 int g_ring_mode = 0;     // experiment hook: 1 = ring kernel without MFMAs, 2 = without DMA (wrong results)
 int g_ring = 1;          // tuning hook: 1 = 3-stage ring kernel for NT products on the 256x128 tile
 int g_stage_mode = 1;    // tuning hook: 0 = LDS-DMA for every operand, 1 = registers for transposed operands
@@ -614,14 +632,20 @@ void launch_cfg(const GemmArgs& g0, int transA, int transB, hipStream_t stream) 
 
 // Tile choice: time ~ rounds(tiles / concurrent blocks) x tile area / relative efficiency.
 int choose_tile(int64_t M, int64_t N, int transA, int transB) {
-  if (g_force_tile >= 0) return (g_force_tile == 3 && transB) ? 0 : g_force_tile;
-  const int bm[4] = {128, 256, 256, 128}, bn[4] = {128, 128, 256, 96};
-  const double slots[4] = {512.0, 256.0, 256.0, 512.0};   // two 4-wave blocks or one 8-wave block per CU
-  // measured on MI355X (tools/bench_gemm.py); the 256x256 half-tile ring exists for NT products only
-  const double eff[4] = {1.0, 0.9, (!transA && !transB && g_ring) ? 1.2 : 1.02, 0.93};
+  const bool nt_ring = !transA && !transB && g_ring;
+  if (g_force_tile >= 0) {
+    if (g_force_tile == 3 && transB) return 0;
+    if (g_force_tile == 4 && !nt_ring) return 2;
+    return g_force_tile;
+  }
+  const int bm[5] = {128, 256, 256, 128, 384}, bn[5] = {128, 128, 256, 96, 192};
+  const double slots[5] = {512.0, 256.0, 256.0, 512.0, 256.0};   // two 4-wave blocks or one 8-wave block per CU
+  // measured on MI355X (tools/bench_gemm.py); the slot-ring kernels exist for NT products only
+  const double eff[5] = {1.0, 0.9, nt_ring ? 1.2 : 1.02, 0.93, 1.2};
   int best = 0;
   double best_cost = 1e300;
-  for (int c = 0; c < (transB ? 3 : 4); ++c) {
+  for (int c = 0; c < 5; ++c) {
+    if ((c == 3 && transB) || (c == 4 && !nt_ring)) continue;
     double tiles = (double)((M + bm[c] - 1) / bm[c]) * (double)((N + bn[c] - 1) / bn[c]);
     double rounds = (double)(int64_t)((tiles + slots[c] - 1) / slots[c]);
     double cost = rounds * slots[c] * bm[c] * bn[c] / eff[c];
@@ -636,9 +660,8 @@ extern "C" int zk_gemm_set_tile(int cfg) {
   if (cfg == 10 || cfg == 11) { g_stage_mode = cfg - 10; return ZK_OK; }
   if (cfg == 20 || cfg == 21) { g_ring = cfg - 20; return ZK_OK; }
   if (cfg >= 30 && cfg <= 33) { g_ring_mode = cfg - 30; return ZK_OK; }
-  if (cfg >= 40 && cfg <= 56) { g_pf = cfg - 40; return ZK_OK; }
   if (cfg >= 100 && cfg <= 116) { g_force_splits = cfg - 100; return ZK_OK; }   // 100 = heuristic, 101 = off
-  if (cfg < -1 || cfg > 3) return ZK_EINVAL;
+  if (cfg < -1 || cfg > 4) return ZK_EINVAL;
   g_force_tile = cfg;
   return ZK_OK;
 }
@@ -662,7 +685,7 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) return ZK_EINVAL;
   if (reinterpret_cast<uintptr_t>(C) & 15) return ZK_EINVAL;
   // 32-bit byte offsets inside one block tile
-  if ((transA ? K : 256) * lda * 2 >= 0x7FFFFFF0LL || (transB ? K : 256) * ldb * 2 >= 0x7FFFFFF0LL) return ZK_EINVAL;
+  if ((transA ? K : 384) * lda * 2 >= 0x7FFFFFF0LL || (transB ? K : 256) * ldb * 2 >= 0x7FFFFFF0LL) return ZK_EINVAL;
   GemmArgs g;
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = (bf16_t*)C;
   g.bias = (const bf16_t*)bias; g.residual = (const bf16_t*)residual;
@@ -673,7 +696,6 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
   g.epilogue = epilogue; g.accumulate = accumulate;
   g.tiles_m = g.tiles_n = 0;
   g.splits = 1; g.kchunk = (int)((K + BK - 1) / BK * BK); g.slab = nullptr;
-  g.pf = g_pf;
   // split-K for small outputs with a long contraction (wgrad, lm_head dgrad): fill the 256 CUs
   const bool plain = epilogue == ZK_EPI_NONE && !bias && !residual && !aux_out;
   if (plain && workspace && g_force_splits != 1) {
@@ -699,19 +721,29 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
   }
   switch (choose_tile(M, N, transA, transB)) {
     case 3: launch_cfg<128, 96, 2, 2>(g, transA, transB, stream); break;
-    case 2:
+    case 4:
+    case 2: {
+      const int tile = choose_tile(M, N, transA, transB);
       if (!transA && !transB && g_ring) {
         GemmArgs gr = g;
-        gr.tiles_m = (g.M + 255) / 256; gr.tiles_n = (g.N + 255) / 256;
+        const int bm = tile == 4 ? 384 : 256, bn = tile == 4 ? 192 : 256;
+        gr.tiles_m = (g.M + bm - 1) / bm; gr.tiles_n = (g.N + bn - 1) / bn;
         const dim3 rg(gr.tiles_m * gr.tiles_n);
-        if (g_ring_mode == 1) hipLaunchKernelGGL((gemm_ring256_kernel<1>), rg, dim3(512), 0, stream, gr);
-        else if (g_ring_mode == 2) hipLaunchKernelGGL((gemm_ring256_kernel<2>), rg, dim3(512), 0, stream, gr);
-        else if (g_ring_mode == 3) hipLaunchKernelGGL((gemm_ring256_kernel<3>), rg, dim3(512), 0, stream, gr);
-        else hipLaunchKernelGGL((gemm_ring256_kernel<0>), rg, dim3(512), 0, stream, gr);
+#define ZK_RINGX(MODE_) \
+  do { \
+    if (tile == 4) hipLaunchKernelGGL((gemm_ringx_kernel<384, 192, 2, 4, 192, 6, MODE_>), rg, dim3(512), 0, stream, gr); \
+    else hipLaunchKernelGGL((gemm_ringx_kernel<256, 256, 2, 4, 256, 5, MODE_>), rg, dim3(512), 0, stream, gr); \
+  } while (0)
+        if (g_ring_mode == 1) ZK_RINGX(1);
+        else if (g_ring_mode == 2) ZK_RINGX(2);
+        else if (g_ring_mode == 3) ZK_RINGX(3);
+        else ZK_RINGX(0);
+#undef ZK_RINGX
       } else {
         launch_cfg<256, 256, 2, 4>(g, transA, transB, stream);
       }
       break;
+    }
     case 1:
       if (!transA && !transB && g_ring) {
         GemmArgs gr = g;
