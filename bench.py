@@ -195,7 +195,8 @@ def main():
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                    "kernel": f"gemm_kernel<transA={int(key[0])},transB={int(key[1])}>",
+                    "kernel": ("NT GEMM family: gemm_ringx_kernel<256,256|384,192> + gemm_kernel small tiles"
+                               if key == (False, False) else f"gemm_kernel<transA={int(key[0])},transB={int(key[1])}>"),
                     "launches_per_step": d["n"] // 2, "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 1),
                     "avg_gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 1),
                     "gemm_ms_per_step": round(sum(v["ms"] for v in fam.values()) / 2, 2),
