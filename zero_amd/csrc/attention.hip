@@ -111,14 +111,18 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // forward
 // =========================================================================================
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   using C = Cfg<HD>;
   constexpr int KV = 64;
   constexpr int TILE = KV * C::ROWB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];  // [buf][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int qblk = gridDim.x - 1 - blockIdx.x;  // heaviest (causal) blocks first
-  const int head = blockIdx.y, b = blockIdx.z;
+  // 1-D grid, heaviest (causal: latest) query blocks first, so the tail of the launch is made of
+  // the short blocks.  (A 3-D grid with the query block on x interleaves heavy and light blocks,
+  // and with 6 query blocks the round-robin over 8 XCDs hands even XCDs only the even ones.)
+  const int nbh = a.Hq * a.B;
+  const int qblk = (int)(gridDim.x / nbh) - 1 - (int)(blockIdx.x / nbh);
+  const int head = (blockIdx.x % nbh) % a.Hq, b = (blockIdx.x % nbh) / a.Hq;
   const int kvh = head / (a.Hq / a.Hkv);
   const int q0 = qblk * 128 + wave * 32;
   const int qi = q0 + (lane & 31);
@@ -274,14 +278,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* o, const 
 // backward: dQ  (per 128-query block, sweep over key tiles)
 // =========================================================================================
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   using C = Cfg<HD>;
   constexpr int KV = 64;
   constexpr int TILE = KV * C::ROWB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int qblk = gridDim.x - 1 - blockIdx.x;
-  const int head = blockIdx.y, b = blockIdx.z;
+  const int nbh = a.Hq * a.B;   // 1-D grid, heaviest query blocks first (see attn_fwd_kernel)
+  const int qblk = (int)(gridDim.x / nbh) - 1 - (int)(blockIdx.x / nbh);
+  const int head = (blockIdx.x % nbh) % a.Hq, b = (blockIdx.x % nbh) / a.Hq;
   const int kvh = head / (a.Hq / a.Hkv);
   const int q0 = qblk * 128 + wave * 32;
   const int qi = q0 + (lane & 31);
@@ -383,14 +388,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 // backward: dK, dV  (per 128-key block of one kv head, sweep over its q heads x query tiles)
 // =========================================================================================
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
   using C = Cfg<HD>;
   constexpr int QT = 32;
   constexpr int TILE = QT * C::ROWB;
   constexpr int STAGE = 2 * TILE + 256;  // Q tile, dO tile, lse2[32], delta[32]
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int kblk = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+  const int nbh = a.Hkv * a.B;  // 1-D grid, heaviest (causal: earliest) key blocks first
+  const int kblk = CAUSAL ? (int)(blockIdx.x / nbh) : (int)(gridDim.x / nbh) - 1 - (int)(blockIdx.x / nbh);
+  const int kvh = (blockIdx.x % nbh) % a.Hkv, b = (blockIdx.x % nbh) / a.Hkv;
   const int rep = a.Hq / a.Hkv;
   const int k0w = kblk * 128 + wave * 32;
   const int ki = k0w + (lane & 31);
@@ -528,7 +535,7 @@ bool bad_attn(int64_t B, int64_t S, int64_t Hq, int64_t Hkv, int64_t hd, int64_t
   if (B <= 0 || S <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv) return true;
   if (hd != 64 && hd != 128) return true;
   if ((l0 | l1 | l2 | l3) & 7) return true;
-  if (B > 65535 || Hq > 65535) return true;
+  if (((S + 127) / 128) * Hq * B > 0x7FFFFFFFLL) return true;
   return false;
 }
 
@@ -542,7 +549,7 @@ extern "C" int zk_attn_fwd(const void* q, const void* k, const void* v, void* o,
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
   a.B = (int)B; a.S = (int)S; a.Hq = (int)Hq; a.Hkv = (int)Hkv;
   a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv; a.ldo = (int)ldo; a.scale = scale;
-  dim3 grid((unsigned)((S + 127) / 128), (unsigned)Hq, (unsigned)B), block(256);
+  dim3 grid((unsigned)(((S + 127) / 128) * Hq * B)), block(256);
   if (head_dim == 64) {
     if (causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, block, 0, stream, a);
@@ -570,8 +577,8 @@ extern "C" int zk_attn_bwd(const void* q, const void* k, const void* v, const vo
   a.lddq = (int)lddq; a.lddk = (int)lddk; a.lddv = (int)lddv; a.scale = scale;
   const int64_t items = B * S * Hq * (head_dim / 8);
   dim3 gd((unsigned)((items + 255) / 256)), block(256);
-  dim3 gq((unsigned)((S + 127) / 128), (unsigned)Hq, (unsigned)B);
-  dim3 gk((unsigned)((S + 127) / 128), (unsigned)Hkv, (unsigned)B);
+  dim3 gq((unsigned)(((S + 127) / 128) * Hq * B));
+  dim3 gk((unsigned)(((S + 127) / 128) * Hkv * B));
   if (head_dim == 64) {
     hipLaunchKernelGGL((attn_delta_kernel<64>), gd, block, 0, stream, a.o, a.d_o, delta, a.B, a.S, a.Hq, a.ldo);
     if (causal) {
