@@ -385,31 +385,71 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // =========================================================================================
-// backward: dK, dV  (per 128-key block of one kv head, sweep over its q heads x query tiles)
+// backward: dK, dV  (per 128-key block of one kv head, sweep over its q heads x 64-query tiles)
+//
+// 8 waves: wave (g, w) owns keys 32w..32w+31 of the block and the rows 32g..32g+31 of every
+// 64-query tile, so two waves per SIMD work on independent halves (one's exp/VALU phase overlaps
+// the other's MFMAs); their dK/dV partial sums meet in LDS at the end.  The Q / dO tiles and the
+// per-row lse / delta arrive by LDS-DMA (buffer_load ... lds, no VGPR staging) into a 4-stage
+// ring: three tiles in flight, one barrier per tile, counted s_waitcnt vmcnt.  The LDS image of a
+// tile is unpadded (the DMA writes 1 KiB lane-linear per wave-instruction); bank conflicts of
+// both read kinds (b128 row fragments, b64 transposed fragments) are removed by XOR-swizzling
+// the 16-byte chunk index on the DMA's SOURCE address and again on the reads.
 // =========================================================================================
+template <int HD>
+__device__ __forceinline__ int swz_key(int row) {
+  if (HD == 128) return ((row & 3) << 2) | ((row >> 2) & 3);
+  return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+}
+template <int HD>
+__device__ __forceinline__ bf16x8 row_frag_sw(const unsigned char* lds, int row0, int ds, int lane) {
+  const int row = row0 + (lane & 31), chunk = ds * 2 + (lane >> 5);
+  return *reinterpret_cast<const bf16x8*>(lds + row * (HD * 2) + ((chunk ^ swz_key<HD>(row)) << 4));
+}
+template <int HD>
+__device__ __forceinline__ bf16x8 tr_frag_sw(const unsigned char* lds, int k0, int s, int db, int lane) {
+  const int h = lane >> 5, i = lane & 15;
+  const int row = k0 + 16 * s + 4 * h + (i >> 2);
+  const int chunk = db * 4 + 2 * ((lane >> 4) & 1) + ((i & 3) >> 1);
+  const int sub = (i & 1) * 8;
+  short4_t lo = lds_read_tr16(lds + row * (HD * 2) + ((chunk ^ swz_key<HD>(row)) << 4) + sub);
+  short4_t hi = lds_read_tr16(lds + (row + 8) * (HD * 2) + ((chunk ^ swz_key<HD>(row + 8)) << 4) + sub);
+  union { struct { short4_t a, b; } s2; bf16x8 v; } u;
+  u.s2.a = lo;
+  u.s2.b = hi;
+  return u.v;
+}
+
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnArgs a) {
   using C = Cfg<HD>;
-  constexpr int QT = 32;
-  constexpr int TILE = QT * C::ROWB;
-  constexpr int STAGE = 2 * TILE + 256;  // Q tile, dO tile, lse2[32], delta[32]
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  constexpr int QT = 64, NST = 3;
+  constexpr int RB = HD * 2;                       // LDS row bytes (unpadded)
+  constexpr int TILE = QT * RB;
+  constexpr int STAGE = 2 * TILE + 2048;           // Q tile, dO tile, 8 x 256 B of per-wave dword DMA (lse, delta, 6 unused)
+  constexpr int VBYTES = 128 * RB;                 // the block's V rows stay in LDS (their fragments would not fit in VGPRs beside K's)
+  constexpr int NQ = QT * C::CPR / 512;            // 16-byte DMA instructions per thread per tile (Q; same for dO)
+  constexpr int PER = 2 * NQ + 1;
+  constexpr int XROW = HD * 4 + 16;                // exchange patch row (fp32 + pad)
+  static_assert(NST * STAGE + VBYTES >= 8 * 32 * XROW, "the dK/dV exchange reuses the ring");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE + VBYTES];
+  unsigned char* const vl = smem + NST * STAGE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int g = wave >> 2, w = wave & 3;
   const int nbh = a.Hkv * a.B;  // 1-D grid, heaviest (causal: earliest) key blocks first
   const int kblk = CAUSAL ? (int)(blockIdx.x / nbh) : (int)(gridDim.x / nbh) - 1 - (int)(blockIdx.x / nbh);
   const int kvh = (blockIdx.x % nbh) % a.Hkv, b = (blockIdx.x % nbh) / a.Hkv;
   const int rep = a.Hq / a.Hkv;
-  const int k0w = kblk * 128 + wave * 32;
+  const int k0w = kblk * 128 + w * 32;
   const int ki = k0w + (lane & 31);
   const bool kok = ki < a.S;
   const float sc = a.scale * LOG2E;
 
-  bf16x8 kf[C::DS], vf[C::DS];
+  bf16x8 kf[C::DS];
   {
     const bf16_t* kp = a.k + ((size_t)b * a.S + ki) * a.ldk + kvh * HD + 8 * h;
-    const bf16_t* vp = a.v + ((size_t)b * a.S + ki) * a.ldv + kvh * HD + 8 * h;
 #pragma unroll
-    for (int ds = 0; ds < C::DS; ++ds) { kf[ds] = gfrag(kp + ds * 16, kok); vf[ds] = gfrag(vp + ds * 16, kok); }
+    for (int ds = 0; ds < C::DS; ++ds) kf[ds] = gfrag(kp + ds * 16, kok);
   }
   f32x16 dk[C::DB], dv[C::DB];
 #pragma unroll
@@ -422,77 +462,88 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
   const int nqt = nqt_all - qt0;
   const int niter = rep * nqt;
 
-  constexpr int NR = (QT * HD / 8 + 255) / 256;   // 2 for HD=128, 1 for HD=64
-  u32x4 rq[NR], rdo[NR];
-  float rl = 0.f, rd = 0.f;
+  // buffer resources over this batch element's rows (32-bit byte offsets; checked on the host)
+  __amdgpu_buffer_rsrc_t rq = make_rsrc(a.q + (size_t)b * a.S * a.ldq, 0x7FFFFFF0u);
+  __amdgpu_buffer_rsrc_t rdo = make_rsrc(a.d_o + (size_t)b * a.S * a.ldo, 0x7FFFFFF0u);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  __amdgpu_buffer_rsrc_t rstat = make_rsrc((wv == 0 ? a.lse_in : a.delta) + (size_t)b * a.Hq * a.S, 0x7FFFFFF0u);
   auto issue = [&](int it) {
+    unsigned char* st = smem + (it % NST) * STAGE;
     const int hq = kvh * rep + it / nqt;
     const int qb = (qt0 + it % nqt) * QT;
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      int c = tid + 256 * i;
-      int row = c / C::CPR, ch = c % C::CPR;
-      bool ok = (c < QT * C::CPR) && (qb + row < a.S);
-      if (ok) {
-        rq[i] = *reinterpret_cast<const u32x4*>(a.q + ((size_t)b * a.S + qb + row) * a.ldq + hq * HD + ch * 8);
-        rdo[i] = *reinterpret_cast<const u32x4*>(a.d_o + ((size_t)b * a.S + qb + row) * a.ldo + hq * HD + ch * 8);
-      } else { rq[i] = u32x4{0u, 0u, 0u, 0u}; rdo[i] = u32x4{0u, 0u, 0u, 0u}; }
+    for (int i = 0; i < NQ; ++i) {
+      const int sidx = tid + 512 * i;
+      const int row = sidx / C::CPR, ch = (sidx % C::CPR) ^ swz_key<HD>(row);
+      const bool ok = qb + row < a.S;
+      unsigned char* dst = st + ((tid & ~63) + 512 * i) * 16;   // wave-uniform; the hardware adds lane * 16
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)dst, 16,
+                                               ok ? (unsigned)(((qb + row) * a.ldq + hq * HD + ch * 8) * 2) : 0xFFFFFFF0u, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (__attribute__((address_space(3))) void*)(dst + TILE), 16,
+                                               ok ? (unsigned)(((qb + row) * a.ldo + hq * HD + ch * 8) * 2) : 0xFFFFFFF0u, 0, 0, 0);
     }
-    if (tid < QT) {
-      bool ok = qb + tid < a.S;
-      size_t st = ((size_t)b * a.Hq + hq) * a.S + qb + (ok ? tid : 0);
-      rl = ok ? a.lse_in[st] * LOG2E : 0.f;
-      rd = ok ? a.delta[st] : 0.f;
-    }
+    // one dword per lane: wave 0 brings lse[qb..qb+63], wave 1 delta[...]; the others a zero fill
+    // (every wave issues the same number of loads, so one counted vmcnt serves all)
+    const bool sok = wv < 2 && qb + lane < a.S;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rstat, (__attribute__((address_space(3))) void*)(st + 2 * TILE + wv * 256), 4,
+                                             sok ? (unsigned)((hq * a.S + qb + lane) * 4) : 0xFFFFFFF0u, 0, 0, 0);
   };
-  auto commit = [&](unsigned char* st) {
+  auto wait_tiles = [&](int n) {   // at most n tiles may stay in flight
+    if (n >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  static_assert(NST == 3, "wait_tiles covers NST - 2 = 1 tile in flight");
+  {
+    // V rows of the block, same swizzled image (issued first: landed before tile 0 is waited for)
+    __amdgpu_buffer_rsrc_t rv = make_rsrc(a.v + (size_t)b * a.S * a.ldv, 0x7FFFFFF0u);
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      int c = tid + 256 * i;
-      if (c < QT * C::CPR) {
-        int row = c / C::CPR, ch = c % C::CPR;
-        *reinterpret_cast<u32x4*>(st + row * C::ROWB + ch * 16) = rq[i];
-        *reinterpret_cast<u32x4*>(st + TILE + row * C::ROWB + ch * 16) = rdo[i];
-      }
+    for (int i = 0; i < 128 * C::CPR / 512; ++i) {
+      const int sidx = tid + 512 * i;
+      const int row = sidx / C::CPR, ch = (sidx % C::CPR) ^ swz_key<HD>(row);
+      const bool ok = kblk * 128 + row < a.S;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(vl + ((tid & ~63) + 512 * i) * 16), 16,
+                                               ok ? (unsigned)(((kblk * 128 + row) * a.ldv + kvh * HD + ch * 8) * 2) : 0xFFFFFFF0u, 0, 0, 0);
     }
-    if (tid < QT) {
-      reinterpret_cast<float*>(st + 2 * TILE)[tid] = rl;
-      reinterpret_cast<float*>(st + 2 * TILE + 128)[tid] = rd;
-    }
-  };
-
-  if (niter > 0) { issue(0); commit(smem); }
-  __syncthreads();
+  }
+  for (int it = 0; it < NST - 1 && it < niter; ++it) issue(it);
 
   for (int it = 0; it < niter; ++it) {
-    const unsigned char* st = smem + (it & 1) * STAGE;
+    // tile `it` has landed (each wave waits for its own pieces, the barrier covers the others'),
+    // and every wave is done with tile it-1, whose stage takes tile it+3
+    wait_tiles(min(NST - 2, niter - 1 - it));
+    __syncthreads();
+    if (it + NST - 1 < niter) issue(it + NST - 1);
+    const unsigned char* st = smem + (it % NST) * STAGE;
     const unsigned char* ql = st;
     const unsigned char* dol = st + TILE;
     const float* lsl = reinterpret_cast<const float*>(st + 2 * TILE);
-    const float* dll = reinterpret_cast<const float*>(st + 2 * TILE + 128);
-    const bool more = it + 1 < niter;
-    if (more) issue(it + 1);
-    const int qb = (qt0 + it % nqt) * QT;
-    // causal: this wave's keys are all after the tile's last query -> nothing to do
-    const bool skip = CAUSAL && (k0w > qb + QT - 1);
+    const float* dll = reinterpret_cast<const float*>(st + 2 * TILE + 256);
+    const int qb = (qt0 + it % nqt) * QT + 32 * g;   // this wave's 32 rows
+    // causal: this wave's keys are all after its last query -> nothing to do; same for rows past S
+    const bool skip = (CAUSAL && (k0w > qb + 31)) || qb >= a.S;
     if (!skip) {
+      // The ~40 swizzled fragment addresses are loop-invariant; hoisted they cost 40 VGPRs the
+      // kernel does not have (spills, whose scratch loads would also break the counted vmcnt).
+      // An opaque copy of the lane id makes the compiler recompute them (2 VALU ops per read).
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int ds = 0; ds < C::DS; ++ds) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(ql, 0, ds, lane), kf[ds], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(dol, 0, ds, lane), vf[ds], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_sw<HD>(ql, 32 * g, ds, ln), kf[ds], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_sw<HD>(dol, 32 * g, ds, ln), row_frag_sw<HD>(vl, 32 * w, ds, ln), dp, 0, 0, 0);
       }
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsl + 8 * r4 + 4 * h);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(dll + 8 * r4 + 4 * h);
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsl + 32 * g + 8 * r4 + 4 * h);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(dll + 32 * g + 8 * r4 + 4 * h);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * r4 + e;
           const int qidx = qb + 8 * r4 + 4 * h + e;
-          float p = fast_exp2(s[r] * sc - l4[e]);
+          float p = fast_exp2(s[r] * sc - l4[e] * LOG2E);
           if (!kok || qidx >= a.S || (CAUSAL && ki > qidx)) p = 0.f;
           s[r] = p;
           dp[r] = p * (dp[r] - d4[e]);
@@ -504,30 +555,52 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
         bf16x8 df = pack_acc(dp, stp);
 #pragma unroll
         for (int d = 0; d < C::DB; ++d) {
-          dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(dol, 0, stp, d, lane), pf, dv[d], 0, 0, 0);
-          dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(ql, 0, stp, d, lane), df, dk[d], 0, 0, 0);
+          dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_sw<HD>(dol, 32 * g, stp, d, ln), pf, dv[d], 0, 0, 0);
+          dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_sw<HD>(ql, 32 * g, stp, d, ln), df, dk[d], 0, 0, 0);
         }
       }
     }
-    if (more) commit(smem + ((it + 1) & 1) * STAGE);
-    __syncthreads();
   }
 
-  if (kok) {
-    bf16_t* kp = a.dk + ((size_t)b * a.S + ki) * a.lddk + kvh * HD;
-    bf16_t* vp = a.dv + ((size_t)b * a.S + ki) * a.lddv + kvh * HD;
+  // ---- the two query halves meet: every wave parks one accumulator set in its fp32 patch
+  // ([32 keys][HD + pad]); wave (g, w) then sums rows 16g..16g+15 of patches (0, w) and (1, w)
+  // and writes whole rows (8 consecutive d per lane).  dK first, then dV through the same patches.
+  float* patch = reinterpret_cast<float*>(smem + wave * (32 * XROW));
+  const float* p0 = reinterpret_cast<const float*>(smem + w * (32 * XROW));
+  const float* p1 = reinterpret_cast<const float*>(smem + (4 + w) * (32 * XROW));
+  constexpr int LPK = HD / 8;          // lanes per key row
+  constexpr int KPP = 64 / LPK;        // keys per pass
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    __syncthreads();                   // ring (or the previous exchange) no longer read
 #pragma unroll
     for (int d = 0; d < C::DB; ++d)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        u32x2 w;
-        w[0] = pack2bf(dk[d][4 * r4] * a.scale, dk[d][4 * r4 + 1] * a.scale);
-        w[1] = pack2bf(dk[d][4 * r4 + 2] * a.scale, dk[d][4 * r4 + 3] * a.scale);
-        *reinterpret_cast<u32x2*>(kp + d * 32 + 8 * r4 + 4 * h) = w;
-        w[0] = pack2bf(dv[d][4 * r4], dv[d][4 * r4 + 1]);
-        w[1] = pack2bf(dv[d][4 * r4 + 2], dv[d][4 * r4 + 3]);
-        *reinterpret_cast<u32x2*>(vp + d * 32 + 8 * r4 + 4 * h) = w;
+        const f32x16& src = which == 0 ? dk[d] : dv[d];
+        f32x4 v4 = {src[4 * r4], src[4 * r4 + 1], src[4 * r4 + 2], src[4 * r4 + 3]};
+        *reinterpret_cast<f32x4*>(patch + (lane & 31) * (XROW / 4) + d * 32 + 8 * r4 + 4 * h) = v4;
       }
+    __syncthreads();
+    const float mul = which == 0 ? a.scale : 1.0f;
+    bf16_t* outp = which == 0 ? a.dk : a.dv;
+    const int ldo_ = which == 0 ? a.lddk : a.lddv;
+#pragma unroll
+    for (int ps = 0; ps < 16 / KPP; ++ps) {
+      const int kr = 16 * g + ps * KPP + lane / LPK, ch = lane % LPK;
+      const int key = kblk * 128 + w * 32 + kr;
+      if (key >= a.S) continue;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(p0 + kr * (XROW / 4) + ch * 8);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(p0 + kr * (XROW / 4) + ch * 8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p1 + kr * (XROW / 4) + ch * 8);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(p1 + kr * (XROW / 4) + ch * 8 + 4);
+      u32x4 o4;
+      o4[0] = pack2bf((a0[0] + b0[0]) * mul, (a0[1] + b0[1]) * mul);
+      o4[1] = pack2bf((a0[2] + b0[2]) * mul, (a0[3] + b0[3]) * mul);
+      o4[2] = pack2bf((a1[0] + b1[0]) * mul, (a1[1] + b1[1]) * mul);
+      o4[3] = pack2bf((a1[2] + b1[2]) * mul, (a1[3] + b1[3]) * mul);
+      *reinterpret_cast<u32x4*>(outp + ((size_t)b * a.S + key) * ldo_ + kvh * HD + ch * 8) = o4;
+    }
   }
 }
 
@@ -568,6 +641,11 @@ extern "C" int zk_attn_bwd(const void* q, const void* k, const void* v, const vo
                            hipStream_t stream) {
   if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv) return ZK_EINVAL;
   if (bad_attn(B, S, Hq, Hkv, head_dim, ldq, ldk, ldv, ldo) || ((lddq | lddk | lddv) & 7)) return ZK_EINVAL;
+  // the dK/dV kernel addresses one batch element's rows with 32-bit byte offsets
+  if (S * ldq * 2 >= 0x7FFFFFF0LL || S * ldo * 2 >= 0x7FFFFFF0LL || S * ldv * 2 >= 0x7FFFFFF0LL ||
+      Hq * S * 4 >= 0x7FFFFFF0LL) return ZK_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(d_o) | reinterpret_cast<uintptr_t>(dk) |
+       reinterpret_cast<uintptr_t>(dv)) & 15) return ZK_EINVAL;
   AttnArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
   a.d_o = (const bf16_t*)d_o; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
@@ -578,24 +656,24 @@ extern "C" int zk_attn_bwd(const void* q, const void* k, const void* v, const vo
   const int64_t items = B * S * Hq * (head_dim / 8);
   dim3 gd((unsigned)((items + 255) / 256)), block(256);
   dim3 gq((unsigned)(((S + 127) / 128) * Hq * B));
-  dim3 gk((unsigned)(((S + 127) / 128) * Hkv * B));
+  dim3 gk((unsigned)(((S + 127) / 128) * Hkv * B)), bk(512);
   if (head_dim == 64) {
     hipLaunchKernelGGL((attn_delta_kernel<64>), gd, block, 0, stream, a.o, a.d_o, delta, a.B, a.S, a.Hq, a.ldo);
     if (causal) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, block, 0, stream, a);
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, true>), gk, block, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, true>), gk, bk, 0, stream, a);
     } else {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false>), gq, block, 0, stream, a);
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, false>), gk, block, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, false>), gk, bk, 0, stream, a);
     }
   } else {
     hipLaunchKernelGGL((attn_delta_kernel<128>), gd, block, 0, stream, a.o, a.d_o, delta, a.B, a.S, a.Hq, a.ldo);
     if (causal) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), gq, block, 0, stream, a);
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, true>), gk, block, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, true>), gk, bk, 0, stream, a);
     } else {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<128, false>), gq, block, 0, stream, a);
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false>), gk, block, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false>), gk, bk, 0, stream, a);
     }
   }
   ZK_CHECK_LAUNCH();
