@@ -437,7 +437,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_ring_kernel(GemmA
 // tail cases merged in, the compiler's s_waitcnt placement assumes the shortest LDS queue and
 // waits for just-issued reads.  MODE 1/2/3 are ablations (no MFMA / no DMA / no epilogue).
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int RS, int NSLOT, int MODE>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int RS, int NSLOT, int MODE, bool LEAN>
 __global__ __launch_bounds__(512) void gemm_ringx_kernel(GemmArgs g) {
   constexpr int NT = 512;
   static_assert(WAVES_M * WAVES_N == 8, "8 waves");
@@ -477,12 +477,33 @@ __global__ __launch_bounds__(512) void gemm_ringx_kernel(GemmArgs g) {
 
   const int nk = (g.K + BK - 1) / BK;
   const int total = nk * SPT;                  // slot loads of the whole K loop, in ring order
-  // slot load q = (K-tile q / SPT, part q % SPT); parts 0..SA-1 are A row blocks, SA.. are B's
+  // slot load q = (K-tile q / SPT, part q % SPT); parts 0..SA-1 are A row blocks, SA.. are B's.
+  // LEAN (host: M % BM == 0, N % BN == 0, K % 64 == 0 - every large product of the step): the
+  // per-lane source offset is ONE register per operand for the whole kernel (instruction i of a
+  // slot reads 64 rows further down: a scalar offset), the LDS address is scalar too, so a K-tile's
+  // DMA costs ~3 scalar instructions per load instead of ~12 VALU ones between the MFMA bursts.
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned voff_a = (unsigned)((tid >> 3) * g.lda + (((tid & 7) ^ ((tid >> 3) & 7)) * 8)) * 2u;
+  const unsigned voff_b = (unsigned)((tid >> 3) * g.ldb + (((tid & 7) ^ ((tid >> 3) & 7)) * 8)) * 2u;
   auto issue = [&](int q) {
     const int t = q / SPT, part = q - t * SPT;
     unsigned char* dst = smem + (q % NSLOT) * SLOT;
-    if (part < SA) tile_dma<false, RS, NT>(rA, dst, g.lda, m0, g.M, t * BK, g.K, tid, part * RS);
-    else tile_dma<false, RS, NT>(rB, dst, g.ldb, n0, g.N, t * BK, g.K, tid, (part - SA) * RS);
+    if constexpr (LEAN) {
+      const bool is_a = part < SA;
+      const int ld = is_a ? g.lda : g.ldb;
+      const int row0 = (is_a ? part : part - SA) * RS;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        unsigned char* d = dst + (wv * 64 + NT * i) * 16;
+        const int soff = ((row0 + 64 * i) * ld + t * BK) * 2;
+        if (is_a) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)d, 16, voff_a, soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)d, 16, voff_b, soff, 0, 0);
+      }
+    } else if (part < SA) {
+      tile_dma<false, RS, NT>(rA, dst, g.lda, m0, g.M, t * BK, g.K, tid, part * RS);
+    } else {
+      tile_dma<false, RS, NT>(rB, dst, g.ldb, n0, g.N, t * BK, g.K, tid, (part - SA) * RS);
+    }
   };
   auto wait_slots = [&](int nslots) {          // at most nslots slot loads may remain in flight
     switch (nslots) {
@@ -609,6 +630,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* slab, b
 namespace {
 int g_force_tile = -1;   // tuning hook: -1 = cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256
 int g_force_splits = 0;  // tuning hook: 0 = heuristic, 1 = never split K, n > 1 = force n splits
+int g_lean = 1;          // experiment hook: 0 = never use the lean DMA path
 int g_ring_mode = 0;     // experiment hook: 1 = ring kernel without MFMAs, 2 = without DMA (wrong results)
 int g_ring = 1;          // tuning hook: 1 = 3-stage ring kernel for NT products on the 256x128 tile
 int g_stage_mode = 1;    // tuning hook: 0 = LDS-DMA for every operand, 1 = registers for transposed operands
@@ -660,6 +682,7 @@ extern "C" int zk_gemm_set_tile(int cfg) {
   if (cfg == 10 || cfg == 11) { g_stage_mode = cfg - 10; return ZK_OK; }
   if (cfg == 20 || cfg == 21) { g_ring = cfg - 20; return ZK_OK; }
   if (cfg >= 30 && cfg <= 33) { g_ring_mode = cfg - 30; return ZK_OK; }
+  if (cfg == 40 || cfg == 41) { g_lean = cfg - 40; return ZK_OK; }
   if (cfg >= 100 && cfg <= 116) { g_force_splits = cfg - 100; return ZK_OK; }   // 100 = heuristic, 101 = off
   if (cfg < -1 || cfg > 4) return ZK_EINVAL;
   g_force_tile = cfg;
@@ -729,10 +752,13 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
         const int bm = tile == 4 ? 384 : 256, bn = tile == 4 ? 192 : 256;
         gr.tiles_m = (g.M + bm - 1) / bm; gr.tiles_n = (g.N + bn - 1) / bn;
         const dim3 rg(gr.tiles_m * gr.tiles_n);
+        const bool lean = g.M % bm == 0 && g.N % bn == 0 && g.K % BK == 0 && g_lean;
 #define ZK_RINGX(MODE_) \
   do { \
-    if (tile == 4) hipLaunchKernelGGL((gemm_ringx_kernel<384, 192, 2, 4, 192, 6, MODE_>), rg, dim3(512), 0, stream, gr); \
-    else hipLaunchKernelGGL((gemm_ringx_kernel<256, 256, 2, 4, 256, 5, MODE_>), rg, dim3(512), 0, stream, gr); \
+    if (tile == 4 && lean) hipLaunchKernelGGL((gemm_ringx_kernel<384, 192, 2, 4, 192, 6, MODE_, true>), rg, dim3(512), 0, stream, gr); \
+    else if (tile == 4) hipLaunchKernelGGL((gemm_ringx_kernel<384, 192, 2, 4, 192, 6, MODE_, false>), rg, dim3(512), 0, stream, gr); \
+    else if (lean) hipLaunchKernelGGL((gemm_ringx_kernel<256, 256, 2, 4, 256, 5, MODE_, true>), rg, dim3(512), 0, stream, gr); \
+    else hipLaunchKernelGGL((gemm_ringx_kernel<256, 256, 2, 4, 256, 5, MODE_, false>), rg, dim3(512), 0, stream, gr); \
   } while (0)
         if (g_ring_mode == 1) ZK_RINGX(1);
         else if (g_ring_mode == 2) ZK_RINGX(2);
