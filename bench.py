@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--gemm-shapes", action="store_true", help="per-shape GEMM table on stderr")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="one-GPU rehearsal of the RCCL path: 1-rank process group, bucket all-reduces still issued")
     return ap.parse_args()
 
 
@@ -69,8 +71,12 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if args.force_dist:   # rehearsal of the RCCL path on one GPU: a 1-rank group, collectives still issued
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ["ZERO_AMD_FORCE_ALLREDUCE"] = "1"
         dist.init_process_group("nccl", device_id=device)
 
     from oracle import zero_oracle as zo   # cpu_baseline leg + synthetic batch generator only
@@ -137,7 +143,7 @@ def main():
         step = lambda: trainer.micro_step(imgs, ids, tgts, img_id, pad_id)
 
     def barrier():
-        if world > 1:
+        if world > 1 or args.force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -149,7 +155,7 @@ def main():
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or args.force_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -256,7 +262,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
 

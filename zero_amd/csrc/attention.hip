@@ -43,55 +43,11 @@ struct AttnArgs {
 
 template <int HD>
 struct Cfg {
-  static constexpr int ROWB = HD * 2 + 16;   // LDS row stride in bytes (16-byte pad: conflict-free b128 row reads)
   static constexpr int CPR = HD / 8;         // 16-byte chunks per row
   static constexpr int DS = HD / 16;         // k-steps over the head dim
   static constexpr int DB = HD / 32;         // 32-wide d blocks
 };
 
-// ---- staging helpers --------------------------------------------------------------------
-// Load ROWS x HD tile (rows of `ld` elements starting at `base`, valid rows < nvalid) into regs.
-template <int HD, int ROWS>
-__device__ __forceinline__ void tile_gload(u32x4 (&r)[ROWS * HD / 8 / 256], const bf16_t* base, int ld, int nvalid,
-                                           int tid) {
-  constexpr int N = ROWS * HD / 8 / 256;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    int c = tid + 256 * i;
-    int row = c / Cfg<HD>::CPR, ch = c % Cfg<HD>::CPR;
-    if (row < nvalid) r[i] = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + ch * 8);
-    else r[i] = u32x4{0u, 0u, 0u, 0u};
-  }
-}
-template <int HD, int ROWS>
-__device__ __forceinline__ void tile_lstore(const u32x4 (&r)[ROWS * HD / 8 / 256], unsigned char* lds, int tid) {
-  constexpr int N = ROWS * HD / 8 / 256;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    int c = tid + 256 * i;
-    int row = c / Cfg<HD>::CPR, ch = c % Cfg<HD>::CPR;
-    *reinterpret_cast<u32x4*>(lds + row * Cfg<HD>::ROWB + ch * 16) = r[i];
-  }
-}
-// MFMA 32x32x16 A/B row fragment: tile row (row0 + lane&31), d = ds*16 + 8*(lane>>5) .. +7
-template <int HD>
-__device__ __forceinline__ bf16x8 row_frag(const unsigned char* lds, int row0, int ds, int lane) {
-  return *reinterpret_cast<const bf16x8*>(lds + (row0 + (lane & 31)) * Cfg<HD>::ROWB + (ds * 16 + 8 * (lane >> 5)) * 2);
-}
-// Transposed A fragment: element j <-> tile row (k0 + 16s + 8(j>>2) + 4h + (j&3)), A-row = column (db*32 + lane&31)
-template <int HD>
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lds, int k0, int s, int db, int lane) {
-  const int h = lane >> 5, i = lane & 15;
-  const int row = k0 + 16 * s + 4 * h + (i >> 2);
-  const int col = db * 32 + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
-  const unsigned char* p = lds + row * Cfg<HD>::ROWB + col * 2;
-  short4_t lo = lds_read_tr16(p);
-  short4_t hi = lds_read_tr16(p + 8 * Cfg<HD>::ROWB);
-  union { struct { short4_t a, b; } s2; bf16x8 v; } u;
-  u.s2.a = lo;
-  u.s2.b = hi;
-  return u.v;
-}
 __device__ __forceinline__ bf16x8 pack_acc(const f32x16& a, int s) {
   bf16x8 r;
 #pragma unroll
@@ -107,16 +63,79 @@ __device__ __forceinline__ bf16x8 gfrag(const bf16_t* p, bool ok) {
 // accumulator register r of lane-half h <-> tile row
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// ---- swizzled, unpadded LDS tiles (filled by LDS-DMA) --------------------------------------
+template <int HD>
+__device__ __forceinline__ int swz_key(int row) {
+  if (HD == 128) return ((row & 3) << 2) | ((row >> 2) & 3);
+  return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+}
+template <int HD>
+__device__ __forceinline__ bf16x8 row_frag_sw(const unsigned char* lds, int row0, int ds, int lane) {
+  const int row = row0 + (lane & 31), chunk = ds * 2 + (lane >> 5);
+  return *reinterpret_cast<const bf16x8*>(lds + row * (HD * 2) + ((chunk ^ swz_key<HD>(row)) << 4));
+}
+template <int HD>
+__device__ __forceinline__ bf16x8 tr_frag_sw(const unsigned char* lds, int k0, int s, int db, int lane) {
+  const int h = lane >> 5, i = lane & 15;
+  const int row = k0 + 16 * s + 4 * h + (i >> 2);
+  const int chunk = db * 4 + 2 * ((lane >> 4) & 1) + ((i & 3) >> 1);
+  const int sub = (i & 1) * 8;
+  short4_t lo = lds_read_tr16(lds + row * (HD * 2) + ((chunk ^ swz_key<HD>(row)) << 4) + sub);
+  short4_t hi = lds_read_tr16(lds + (row + 8) * (HD * 2) + ((chunk ^ swz_key<HD>(row + 8)) << 4) + sub);
+  union { struct { short4_t a, b; } s2; bf16x8 v; } u;
+  u.s2.a = lo;
+  u.s2.b = hi;
+  return u.v;
+}
+
 // =========================================================================================
-// forward
+// forward and dQ share the K/V stream: 64-key tiles (K rows then V rows, unpadded, chunk-swizzled,
+// see swz_key) brought in by LDS-DMA into a ring of NST stages; 4 waves x 32 queries per block,
+// two blocks per CU.  One barrier per tile: "tile t landed everywhere and tile t-1 is consumed",
+// after which the stage of tile t-1 is refilled with tile t+NST-1.
 // =========================================================================================
+template <int HD>
+struct KvRing {
+  static constexpr int KV = 64;
+  static constexpr int RB = HD * 2;
+  static constexpr int TILE = KV * RB;
+  static constexpr int STAGE = 2 * TILE;
+  static constexpr int NST = HD == 128 ? 2 : 4;            // 64 KiB per block either way
+  static constexpr int NQ = KV * (HD / 8) / 256;           // 16-byte DMA instructions per thread per operand tile
+  static constexpr int PER = 2 * NQ;
+
+  __device__ static __forceinline__ void issue(unsigned char* smem, __amdgpu_buffer_rsrc_t rk, __amdgpu_buffer_rsrc_t rv,
+                                               int t, int S, int ldk, int ldv, int col0, int tid, int wv) {
+    unsigned char* st = smem + (t % NST) * STAGE;
+    const int kn = t * KV;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int sidx = tid + 256 * i;
+      const int row = sidx / (HD / 8), ch = (sidx % (HD / 8)) ^ swz_key<HD>(row);
+      const bool ok = kn + row < S;
+      unsigned char* dst = st + (wv * 64 + 256 * i) * 16;   // wave-uniform; the hardware adds lane * 16
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)dst, 16,
+                                               ok ? (unsigned)(((kn + row) * ldk + col0 + ch * 8) * 2) : 0xFFFFFFF0u, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(dst + TILE), 16,
+                                               ok ? (unsigned)(((kn + row) * ldv + col0 + ch * 8) * 2) : 0xFFFFFFF0u, 0, 0, 0);
+    }
+  }
+  // at most n tiles may stay in flight (n <= NST - 2)
+  __device__ static __forceinline__ void wait_tiles(int n) {
+    if (NST >= 4 && n >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    else if (NST >= 3 && n >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+};
+
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   using C = Cfg<HD>;
-  constexpr int KV = 64;
-  constexpr int TILE = KV * C::ROWB;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];  // [buf][K|V]
+  using R = KvRing<HD>;
+  constexpr int KV = R::KV;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[R::NST * R::STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
   // 1-D grid, heaviest (causal: latest) query blocks first, so the tail of the launch is made of
   // the short blocks.  (A 3-D grid with the query block on x interleaves heavy and light blocks,
   // and with 6 query blocks the round-robin over 8 XCDs hands even XCDs only the even ones.)
@@ -128,104 +147,84 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   const int qi = q0 + (lane & 31);
   const float sc = a.scale * LOG2E;
 
-  const bf16_t* kbase = a.k + (size_t)b * a.S * a.ldk + kvh * HD;
-  const bf16_t* vbase = a.v + (size_t)b * a.S * a.ldv + kvh * HD;
+  __amdgpu_buffer_rsrc_t rk = make_rsrc(a.k + (size_t)b * a.S * a.ldk, 0x7FFFFFF0u);
+  __amdgpu_buffer_rsrc_t rv = make_rsrc(a.v + (size_t)b * a.S * a.ldv, 0x7FFFFFF0u);
+  int kv_end = a.S;
+  if (CAUSAL) kv_end = min(a.S, qblk * 128 + 128);
+  const int nt = (kv_end + KV - 1) / KV;
+  int nt_wave = nt;
+  if (CAUSAL) nt_wave = min(nt, (q0 + 32 + KV - 1) / KV);
+  for (int t = 0; t < R::NST - 1 && t < nt; ++t) R::issue(smem, rk, rv, t, a.S, a.ldk, a.ldv, kvh * HD, tid, wv);
+
   bf16x8 qf[C::DS];
   {
     const bf16_t* qp = a.q + ((size_t)b * a.S + qi) * a.ldq + head * HD + 8 * h;
 #pragma unroll
     for (int ds = 0; ds < C::DS; ++ds) qf[ds] = gfrag(qp + ds * 16, qi < a.S);
   }
-  int kv_end = a.S;
-  if (CAUSAL) kv_end = min(a.S, qblk * 128 + 128);
-  const int nt = (kv_end + KV - 1) / KV;
-  int nt_wave = nt;
-  if (CAUSAL) nt_wave = min(nt, (q0 + 32 + KV - 1) / KV);
-
   f32x16 o[C::DB];
 #pragma unroll
   for (int d = 0; d < C::DB; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  constexpr int NR = KV * HD / 8 / 256;
-  u32x4 rk[NR], rv[NR];
-  tile_gload<HD, KV>(rk, kbase, a.ldk, a.S, tid);
-  tile_gload<HD, KV>(rv, vbase, a.ldv, a.S, tid);
-  tile_lstore<HD, KV>(rk, smem, tid);
-  tile_lstore<HD, KV>(rv, smem + TILE, tid);
-  __syncthreads();
+  float m_run = -INFINITY, l_run = 0.f;   // running max in the scaled log2 domain
 
   for (int t = 0; t < nt; ++t) {
-    const unsigned char* kl = smem + (t & 1) * 2 * TILE;
-    const unsigned char* vl = kl + TILE;
-    const bool more = t + 1 < nt;
-    if (more) {
-      const int kn = (t + 1) * KV;
-      tile_gload<HD, KV>(rk, kbase + (size_t)kn * a.ldk, a.ldk, a.S - kn, tid);
-      tile_gload<HD, KV>(rv, vbase + (size_t)kn * a.ldv, a.ldv, a.S - kn, tid);
-    }
-    if (t < nt_wave) {
-      const int k0 = t * KV;
-      f32x16 s[2];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
-        for (int ds = 0; ds < C::DS; ++ds)
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(kl, kb * 32, ds, lane), qf[ds], s[kb], 0, 0, 0);
-      }
-      const bool need_mask = (k0 + KV > a.S) || (CAUSAL && (k0 + KV - 1 > q0));
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float val = s[kb][r] * sc;
-          if (need_mask) {
-            int key = k0 + kb * 32 + acc_row(r, h);
-            if (key >= a.S || (CAUSAL && key > qi)) val = -INFINITY;
-          }
-          s[kb][r] = val;
-          mx = fmaxf(mx, val);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = fast_exp2(m_run - m_use);
-      float rs = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float p = fast_exp2(s[kb][r] - m_use);
-          s[kb][r] = p;
-          rs += p;
-        }
-      l_run = l_run * alpha + rs;
-      m_run = m_new;
-#pragma unroll
-      for (int d = 0; d < C::DB; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-          bf16x8 pf = pack_acc(s[kb], st);
-#pragma unroll
-          for (int d = 0; d < C::DB; ++d)
-            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(vl, kb * 32, st, d, lane), pf, o[d], 0, 0, 0);
-        }
-    }
-    if (more) {
-      unsigned char* nx = smem + ((t + 1) & 1) * 2 * TILE;
-      tile_lstore<HD, KV>(rk, nx, tid);
-      tile_lstore<HD, KV>(rv, nx + TILE, tid);
-    }
+    R::wait_tiles(min(R::NST - 2, nt - 1 - t));
     __syncthreads();
+    if (t + R::NST - 1 < nt) R::issue(smem, rk, rv, t + R::NST - 1, a.S, a.ldk, a.ldv, kvh * HD, tid, wv);
+    if (t >= nt_wave) continue;
+    const unsigned char* kl = smem + (t % R::NST) * R::STAGE;
+    const unsigned char* vl = kl + R::TILE;
+    const int k0 = t * KV;
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < C::DS; ++ds)
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_sw<HD>(kl, kb * 32, ds, lane), qf[ds], s[kb], 0, 0, 0);
+    }
+    // raw scores; the softmax scale rides in the exponent's fma
+    if ((k0 + KV > a.S) || (CAUSAL && (k0 + KV - 1 > q0))) {   // wave-uniform: only edge / diagonal tiles mask
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + kb * 32 + acc_row(r, h);
+          if (key >= a.S || (CAUSAL && key > qi)) s[kb][r] = -INFINITY;
+        }
+    }
+    float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * sc);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = fast_exp2(m_run - m_use);
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(__builtin_fmaf(s[kb][r], sc, -m_use));
+        s[kb][r] = p;
+        rs += p;
+      }
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < C::DB; ++d) o[d] = o[d] * alpha;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        bf16x8 pf = pack_acc(s[kb], st);
+#pragma unroll
+        for (int d = 0; d < C::DB; ++d)
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_sw<HD>(vl, kb * 32, st, d, lane), pf, o[d], 0, 0, 0);
+      }
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -275,15 +274,16 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* o, const 
 }
 
 // =========================================================================================
-// backward: dQ  (per 128-query block, sweep over key tiles)
+// backward: dQ  (per 128-query block, sweep over key tiles; same K/V ring as the forward)
 // =========================================================================================
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   using C = Cfg<HD>;
-  constexpr int KV = 64;
-  constexpr int TILE = KV * C::ROWB;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];
+  using R = KvRing<HD>;
+  constexpr int KV = R::KV;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[R::NST * R::STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int nbh = a.Hq * a.B;   // 1-D grid, heaviest query blocks first (see attn_fwd_kernel)
   const int qblk = (int)(gridDim.x / nbh) - 1 - (int)(blockIdx.x / nbh);
   const int head = (blockIdx.x % nbh) % a.Hq, b = (blockIdx.x % nbh) / a.Hq;
@@ -293,8 +293,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const float sc = a.scale * LOG2E;
   const bool qok = qi < a.S;
 
-  const bf16_t* kbase = a.k + (size_t)b * a.S * a.ldk + kvh * HD;
-  const bf16_t* vbase = a.v + (size_t)b * a.S * a.ldv + kvh * HD;
+  __amdgpu_buffer_rsrc_t rk = make_rsrc(a.k + (size_t)b * a.S * a.ldk, 0x7FFFFFF0u);
+  __amdgpu_buffer_rsrc_t rv = make_rsrc(a.v + (size_t)b * a.S * a.ldv, 0x7FFFFFF0u);
+  int kv_end = a.S;
+  if (CAUSAL) kv_end = min(a.S, qblk * 128 + 128);
+  const int nt = (kv_end + KV - 1) / KV;
+  int nt_wave = nt;
+  if (CAUSAL) nt_wave = min(nt, (q0 + 32 + KV - 1) / KV);
+  for (int t = 0; t < R::NST - 1 && t < nt; ++t) R::issue(smem, rk, rv, t, a.S, a.ldk, a.ldv, kvh * HD, tid, wv);
+
   bf16x8 qf[C::DS], dof[C::DS];
   {
     const bf16_t* qp = a.q + ((size_t)b * a.S + qi) * a.ldq + head * HD + 8 * h;
@@ -302,15 +309,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int ds = 0; ds < C::DS; ++ds) { qf[ds] = gfrag(qp + ds * 16, qok); dof[ds] = gfrag(dp + ds * 16, qok); }
   }
+  // rows past S: q = dO = 0 gives s = dP = 0, p = 1, dS = 0: harmless, and never stored
   const size_t stat = ((size_t)b * a.Hq + head) * a.S + (qok ? qi : 0);
   const float lse2 = qok ? a.lse_in[stat] * LOG2E : 0.f;
   const float dlt = qok ? a.delta[stat] : 0.f;
-
-  int kv_end = a.S;
-  if (CAUSAL) kv_end = min(a.S, qblk * 128 + 128);
-  const int nt = (kv_end + KV - 1) / KV;
-  int nt_wave = nt;
-  if (CAUSAL) nt_wave = min(nt, (q0 + 32 + KV - 1) / KV);
 
   f32x16 dq[C::DB];
 #pragma unroll
@@ -318,57 +320,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
 
-  constexpr int NR = KV * HD / 8 / 256;
-  u32x4 rk[NR], rv[NR];
-  tile_gload<HD, KV>(rk, kbase, a.ldk, a.S, tid);
-  tile_gload<HD, KV>(rv, vbase, a.ldv, a.S, tid);
-  tile_lstore<HD, KV>(rk, smem, tid);
-  tile_lstore<HD, KV>(rv, smem + TILE, tid);
-  __syncthreads();
-
   for (int t = 0; t < nt; ++t) {
-    const unsigned char* kl = smem + (t & 1) * 2 * TILE;
-    const unsigned char* vl = kl + TILE;
-    const bool more = t + 1 < nt;
-    if (more) {
-      const int kn = (t + 1) * KV;
-      tile_gload<HD, KV>(rk, kbase + (size_t)kn * a.ldk, a.ldk, a.S - kn, tid);
-      tile_gload<HD, KV>(rv, vbase + (size_t)kn * a.ldv, a.ldv, a.S - kn, tid);
-    }
-    if (t < nt_wave) {
-      const int k0 = t * KV;
+    R::wait_tiles(min(R::NST - 2, nt - 1 - t));
+    __syncthreads();
+    if (t + R::NST - 1 < nt) R::issue(smem, rk, rv, t + R::NST - 1, a.S, a.ldk, a.ldv, kvh * HD, tid, wv);
+    if (t >= nt_wave) continue;
+    const unsigned char* kl = smem + (t % R::NST) * R::STAGE;
+    const unsigned char* vl = kl + R::TILE;
+    const int k0 = t * KV;
+    const bool need_mask = (k0 + KV > a.S) || (CAUSAL && (k0 + KV - 1 > q0));   // wave-uniform
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        f32x16 s, dp;
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s, dp;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int ds = 0; ds < C::DS; ++ds) {
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(kl, kb * 32, ds, lane), qf[ds], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(vl, kb * 32, ds, lane), dof[ds], dp, 0, 0, 0);
+      for (int ds = 0; ds < C::DS; ++ds) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_sw<HD>(kl, kb * 32, ds, lane), qf[ds], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_sw<HD>(vl, kb * 32, ds, lane), dof[ds], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = fast_exp2(__builtin_fmaf(s[r], sc, -lse2));
+        if (need_mask) {
+          const int key = k0 + kb * 32 + acc_row(r, h);
+          if (key >= a.S || (CAUSAL && key > qi)) p = 0.f;
         }
+        s[r] = p * (dp[r] - dlt);   // dS^T (without the softmax scale)
+      }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int key = k0 + kb * 32 + acc_row(r, h);
-          float p = fast_exp2(s[r] * sc - lse2);
-          if (key >= a.S || !qok || (CAUSAL && key > qi)) p = 0.f;
-          s[r] = p * (dp[r] - dlt);   // dS^T (without the softmax scale)
-        }
+      for (int st = 0; st < 2; ++st) {
+        bf16x8 df = pack_acc(s, st);
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-          bf16x8 df = pack_acc(s, st);
-#pragma unroll
-          for (int d = 0; d < C::DB; ++d)
-            dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(kl, kb * 32, st, d, lane), df, dq[d], 0, 0, 0);
-        }
+        for (int d = 0; d < C::DB; ++d)
+          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_sw<HD>(kl, kb * 32, st, d, lane), df, dq[d], 0, 0, 0);
       }
     }
-    if (more) {
-      unsigned char* nx = smem + ((t + 1) & 1) * 2 * TILE;
-      tile_lstore<HD, KV>(rk, nx, tid);
-      tile_lstore<HD, KV>(rv, nx + TILE, tid);
-    }
-    __syncthreads();
   }
   if (qok) {
     bf16_t* op = a.dq + ((size_t)b * a.S + qi) * a.lddq + head * HD;
@@ -396,30 +383,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 // both read kinds (b128 row fragments, b64 transposed fragments) are removed by XOR-swizzling
 // the 16-byte chunk index on the DMA's SOURCE address and again on the reads.
 // =========================================================================================
-template <int HD>
-__device__ __forceinline__ int swz_key(int row) {
-  if (HD == 128) return ((row & 3) << 2) | ((row >> 2) & 3);
-  return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
-}
-template <int HD>
-__device__ __forceinline__ bf16x8 row_frag_sw(const unsigned char* lds, int row0, int ds, int lane) {
-  const int row = row0 + (lane & 31), chunk = ds * 2 + (lane >> 5);
-  return *reinterpret_cast<const bf16x8*>(lds + row * (HD * 2) + ((chunk ^ swz_key<HD>(row)) << 4));
-}
-template <int HD>
-__device__ __forceinline__ bf16x8 tr_frag_sw(const unsigned char* lds, int k0, int s, int db, int lane) {
-  const int h = lane >> 5, i = lane & 15;
-  const int row = k0 + 16 * s + 4 * h + (i >> 2);
-  const int chunk = db * 4 + 2 * ((lane >> 4) & 1) + ((i & 3) >> 1);
-  const int sub = (i & 1) * 8;
-  short4_t lo = lds_read_tr16(lds + row * (HD * 2) + ((chunk ^ swz_key<HD>(row)) << 4) + sub);
-  short4_t hi = lds_read_tr16(lds + (row + 8) * (HD * 2) + ((chunk ^ swz_key<HD>(row + 8)) << 4) + sub);
-  union { struct { short4_t a, b; } s2; bf16x8 v; } u;
-  u.s2.a = lo;
-  u.s2.b = hi;
-  return u.v;
-}
-
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnArgs a) {
   using C = Cfg<HD>;
@@ -618,6 +581,9 @@ extern "C" int zk_attn_fwd(const void* q, const void* k, const void* v, void* o,
                            int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv,
                            int64_t ldo, float scale, int causal, hipStream_t stream) {
   if (!q || !k || !v || !o || bad_attn(B, S, Hq, Hkv, head_dim, ldq, ldk, ldv, ldo)) return ZK_EINVAL;
+  // K / V rows of one batch element are addressed with 32-bit byte offsets by the LDS-DMA
+  if (S * ldk * 2 >= 0x7FFFFFF0LL || S * ldv * 2 >= 0x7FFFFFF0LL) return ZK_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) return ZK_EINVAL;
   AttnArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
   a.B = (int)B; a.S = (int)S; a.Hq = (int)Hq; a.Hkv = (int)Hkv;
@@ -642,9 +608,9 @@ extern "C" int zk_attn_bwd(const void* q, const void* k, const void* v, const vo
   if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv) return ZK_EINVAL;
   if (bad_attn(B, S, Hq, Hkv, head_dim, ldq, ldk, ldv, ldo) || ((lddq | lddk | lddv) & 7)) return ZK_EINVAL;
   // the dK/dV kernel addresses one batch element's rows with 32-bit byte offsets
-  if (S * ldq * 2 >= 0x7FFFFFF0LL || S * ldo * 2 >= 0x7FFFFFF0LL || S * ldv * 2 >= 0x7FFFFFF0LL ||
+  if (S * ldq * 2 >= 0x7FFFFFF0LL || S * ldo * 2 >= 0x7FFFFFF0LL || S * ldv * 2 >= 0x7FFFFFF0LL || S * ldk * 2 >= 0x7FFFFFF0LL ||
       Hq * S * 4 >= 0x7FFFFFF0LL) return ZK_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(d_o) | reinterpret_cast<uintptr_t>(dk) |
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(d_o) | reinterpret_cast<uintptr_t>(dk) |
        reinterpret_cast<uintptr_t>(dv)) & 15) return ZK_EINVAL;
   AttnArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;

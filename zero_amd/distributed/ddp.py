@@ -16,6 +16,7 @@ Design (MI355X / RCCL over xGMI):
 """
 from __future__ import annotations
 
+import os
 from contextlib import contextmanager
 from typing import Dict, List, Optional
 
@@ -58,6 +59,9 @@ class FlatGradReducer:
     def __init__(self, model: nn.Module, bucket_bytes: int = 25 * 1024 * 1024, process_group=None):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # one-GPU rehearsal of the collective path (bench.py --force-dist): issue the all-reduces
+        # of a 1-rank group instead of skipping them
+        self._force = dist.is_initialized() and os.environ.get("ZERO_AMD_FORCE_ALLREDUCE") == "1"
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         if not named:
             raise ValueError("no trainable parameters: call func_optim_filter before building the reducer")
@@ -133,7 +137,7 @@ class FlatGradReducer:
             self._launch(i)
 
     def _launch(self, i):
-        if self._launched[i] or self.world == 1:
+        if self._launched[i] or (self.world == 1 and not self._force):
             self._launched[i] = True
             return
         b = self.buckets[i]
