@@ -97,6 +97,8 @@ def main():
         cfg.translators_range = LLAMA_SHAPES[("3.1", "8")]["translators_range"]
     B = args.batch or (64 if args.workload == "c2" else 8)
     cfg.batch_size = B
+    if os.environ.get("ZERO_AMD_NAN_CHECK"):      # A/B hook: "sync" = the reference's blocking check
+        cfg.check_nan_loss = os.environ["ZERO_AMD_NAN_CHECK"]
 
     # ---- model: identical seeded random init on every rank (DDP broadcasts rank 0's weights)
     torch.manual_seed(1337)
@@ -150,11 +152,28 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if rank == 0 and os.environ.get("ZERO_AMD_BENCH_CPROFILE"):
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        torch.cuda.synchronize()
+        pr.enable()
+        for _ in range(3):
+            step()
+        pr.disable()
+        torch.cuda.synchronize()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(28)
     t0 = time.perf_counter()
+    host_s = 0.0
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         loss = step()
+        host_s += time.perf_counter() - h0
     barrier()
     dt = time.perf_counter() - t0
+    if rank == 0 and os.environ.get("ZERO_AMD_BENCH_VERBOSE"):
+        # host-side enqueue time per step (the step never synchronises; if this approaches ms_per_step
+        # the GPU is waiting for Python)
+        print(f"host enqueue {host_s / args.steps * 1e3:.2f} ms/step", file=sys.stderr)
     if world > 1 or args.force_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

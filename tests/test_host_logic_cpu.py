@@ -154,3 +154,13 @@ def test_flat_reducer_layout_cpu():
         assert r.buckets[0]["start"] == 0 and r.buckets[-1]["end"] == r.numel
     finally:
         r.close()
+
+
+def test_nan_watch_raises_like_the_reference_on_cpu():
+    """engine:315-316: a NaN loss is a ValueError (on the CPU path immediately; on the GPU the flag is
+    read back asynchronously, see _NanWatch)."""
+    from zero_amd.methods.engine_ar_instruction_llama import _NanWatch
+    w = _NanWatch()
+    w.check_and_arm(torch.tensor(1.0), torch.device("cpu"))
+    with pytest.raises(ValueError, match="NaN"):
+        w.check_and_arm(torch.tensor(float("nan")), torch.device("cpu"))

@@ -199,3 +199,20 @@ def test_trainer_step_updates_and_accumulates():
         assert moved > 6 and not bad, bad
     finally:
         tr.reducer.close()
+
+
+def test_nan_loss_is_reported_without_a_per_step_sync():
+    """engine:315-316 raises on a NaN loss; here the flag is read back asynchronously (no GPU drain
+    between forward and backward) and surfaces at a later check or at flush()."""
+    from zero_amd.methods.engine_ar_instruction_llama import _NanWatch
+    w = _NanWatch()
+    dev = torch.device("cuda", 0)
+    w.check_and_arm(torch.tensor(2.0, device=dev), dev)
+    w.flush()
+    w.check_and_arm(torch.tensor(float("nan"), device=dev), dev)
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="NaN"):
+        w.check_and_arm(torch.tensor(1.0, device=dev), dev)
+    w.check_and_arm(torch.tensor(float("nan"), device=dev), dev)
+    with pytest.raises(ValueError, match="NaN"):
+        w.flush()

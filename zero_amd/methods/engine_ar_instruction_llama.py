@@ -146,6 +146,51 @@ def build_plan(input_ids, targets, n_img_rows: Sequence[int], img_id: int, pad_i
                 labels_full=flat.astype(np.int32))
 
 
+class _NanWatch:
+    """engine:315-316 raises ValueError when the loss is NaN.  Reading the loss on the host right
+    after the forward drains the GPU once per step (the backward cannot be enqueued behind it), so
+    the flag travels to pinned host memory asynchronously and is examined, without blocking, at the
+    next forward(s): the error is raised one or two steps late instead of stalling every step.
+    ``cfg.check_nan_loss = "sync"`` restores the reference's immediate check."""
+
+    def __init__(self):
+        self.pending = []      # (event, pinned flag)
+
+    def check_and_arm(self, loss, device, sync: bool = False):
+        keep = []
+        for ev, flag in self.pending:
+            if ev.query():
+                if bool(flag.item()):
+                    self.pending = []
+                    rank = dist.get_rank() if dist.is_initialized() else 0
+                    raise ValueError(f"loss is NaN on rank {rank}")
+            else:
+                keep.append((ev, flag))
+        self.pending = keep[-8:]
+        if device.type != "cuda":
+            if bool(loss.isnan()):
+                rank = dist.get_rank() if dist.is_initialized() else 0
+                raise ValueError(f"loss is NaN on rank {rank}")
+            return
+        flag = torch.empty(1, dtype=torch.bool).pin_memory()
+        flag.copy_(loss.detach().isnan().reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((ev, flag))
+
+    def flush(self):
+        """Blocking check of everything in flight (end of training / tests)."""
+        pend, self.pending = self.pending, []
+        for ev, flag in pend:
+            ev.synchronize()
+            if bool(flag.item()):
+                rank = dist.get_rank() if dist.is_initialized() else 0
+                raise ValueError(f"loss is NaN on rank {rank}")
+
+
+_NAN_WATCH = _NanWatch()
+
+
 def _upload(plan, device, keys):
     """One host->device copy for all int32 index arrays."""
     parts = [plan[k] for k in keys]
@@ -162,8 +207,9 @@ def forward_from_ids(self, cfg, imgs: List[torch.Tensor], input_ids, targets, im
     rows, split_sizes, T = self._encode_rows(imgs)                       # engine:49
     plan = build_plan(input_ids, targets, [p * T for p in split_sizes], img_id, pad_id, cfg.max_seq_len)
     B, S = plan["B"], plan["S"]
+    plan["n_valid_arr"] = np.asarray([plan["n_valid"]], dtype=np.int32)
     dev = _upload(plan, device, ["codes", "rows", "row_labels", "inv_rows", "inv_codes", "soi_pos", "eoi_pos",
-                                 "labels_full"])
+                                 "labels_full", "n_valid_arr"])
     wte = self.decoder.model.get_input_embeddings().weight                # engine:186
     inputs_embeds = ZF.SpliceFn.apply(rows, self.embd_soi, self.embd_eoi, wte.detach(), dev["codes"],
                                       dev["inv_codes"], dev["soi_pos"], dev["eoi_pos"], B, S)
@@ -177,14 +223,18 @@ def forward_from_ids(self, cfg, imgs: List[torch.Tensor], input_ids, targets, im
     else:   # any module with the HF call contract (engine:276-280)
         logits = dec(inputs_embeds=inputs_embeds, use_cache=False)["logits"]
         loss = ZF.CrossEntropySumFn.apply(logits.reshape(B * S, -1), dev["labels_full"])
-    num_tokens = torch.tensor(plan["n_valid"], dtype=torch.int64, device=device)
+    num_tokens = dev["n_valid_arr"][0].to(torch.int64)                    # rides in the one pinned upload: no sync
     loss_sum_local = loss.detach()
     if cfg.reduce_batch_loss:                                             # engine:308-310
         loss, num_tokens = reduce_sum_pair(loss, num_tokens)
     loss = loss / num_tokens                                              # engine:313
-    if getattr(cfg, "check_nan_loss", True) and loss.isnan():             # engine:315-316
-        rank = dist.get_rank() if dist.is_initialized() else 0
-        raise ValueError(f"loss is NaN on rank {rank}")
+    chk = getattr(cfg, "check_nan_loss", True)
+    if chk == "sync":                                                     # engine:315-316, as the reference does it
+        if loss.isnan():
+            rank = dist.get_rank() if dist.is_initialized() else 0
+            raise ValueError(f"loss is NaN on rank {rank}")
+    elif chk:
+        _NAN_WATCH.check_and_arm(loss, device)
     if return_aux:
         return loss, dict(inputs_embeds=inputs_embeds, target=torch.from_numpy(plan["target"]), logits=logits,
                           loss_sum=loss_sum_local, num_tokens=num_tokens, plan=plan, img_rows=rows)
