@@ -51,7 +51,19 @@ enum {
   ZK_EPI_QUICK_GELU = 1,
   ZK_EPI_GELU_ERF = 2,
   ZK_EPI_MUL_DQUICK_GELU = 3,
-  ZK_EPI_MUL_DGELU_ERF = 4
+  ZK_EPI_MUL_DGELU_ERF = 4,
+  /* SwiGLU fused into the two GEMMs around it (tf:llama:174-176, frozen surrogate MLP).  The gate|up
+   * product is kept in a BLOCK-INTERLEAVED column order: columns [64j, 64j+32) are gate features
+   * 32j..32j+31, columns [64j+32, 64j+64) the matching up features (the caller interleaves the
+   * weight rows once; any K order is fine for the dgrad that follows as long as both operands agree).
+   *   ZK_EPI_SWIGLU     : C[M][N = 2F] = interleaved gate|up (saved for backward), and
+   *                       aux_out[M][F] (row stride ldaux) = bf16(silu(gate)) * up.
+   *   ZK_EPI_SWIGLU_BWD : the GEMM computes dh[M][N = F]; C[M][2F] (interleaved, row stride ldc) gets
+   *                       dgate = dh * up * silu'(gate), dup = dh * silu(gate); aux_in[M][2F] = the
+   *                       interleaved gate|up of the forward (row stride ldaux).
+   * Both: alpha = 1, no bias / residual / accumulate. */
+  ZK_EPI_SWIGLU = 5,
+  ZK_EPI_SWIGLU_BWD = 6
 };
 int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K,
                  int64_t lda, int64_t ldb, int64_t ldc, int transA, int transB, int epilogue,

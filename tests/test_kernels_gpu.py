@@ -123,6 +123,31 @@ def test_gemm_epilogues(gemm_tile):
     assert relerr(got, base * hf.grad) < 8e-3
 
 
+@pytest.mark.parametrize("M,F,K", [(300, 96, 136), (512, 256, 192), (130, 32, 64)])
+def test_gemm_fused_swiglu_matches_unfused(M, F, K, gemm_tile):
+    """ZK_EPI_SWIGLU / ZK_EPI_SWIGLU_BWD against the separate kernels: bit-identical (same roundings)."""
+    x, gw, uw = rnd(M, K, seed=41), rnd(F, K, seed=42, scale=0.2), rnd(F, K, seed=43, scale=0.2)
+    wgu = torch.cat((gw, uw), 0)
+    gu_ref = ops.gemm(x, wgu)
+    h_ref = ops.swiglu_fwd(gu_ref, F)
+    wi = ops.interleave_gate_up(gw, uw)
+    gu_i, h = ops.gemm_swiglu(x, wi)
+    blk = gu_i.view(M, F // 32, 2, 32)
+    assert torch.equal(blk[:, :, 0].reshape(M, F), gu_ref[:, :F]) and torch.equal(blk[:, :, 1].reshape(M, F), gu_ref[:, F:])
+    assert torch.equal(h, h_ref)
+    # backward: dh = dy @ Wd (Wd [D, F]) then SwiGLU'
+    D = 72
+    dy, wd = rnd(M, D, seed=44), rnd(D, F, seed=45, scale=0.2)
+    dgu_ref = ops.swiglu_bwd(ops.gemm(dy, wd, trans_b=True), gu_ref, F)
+    dgu_i = ops.gemm_swiglu_bwd(dy, wd.t().contiguous(), gu_i)
+    blk = dgu_i.view(M, F // 32, 2, 32)
+    assert torch.equal(blk[:, :, 0].reshape(M, F), dgu_ref[:, :F]) and torch.equal(blk[:, :, 1].reshape(M, F), dgu_ref[:, F:])
+    # the dgrad that follows contracts over the interleaved order on both operands
+    dx_ref = ops.gemm(dgu_ref, wgu, trans_b=True)
+    dx = ops.gemm(dgu_i, wi.t().contiguous())
+    assert relerr(dx, dx_ref.float()) < 6e-3
+
+
 @pytest.mark.parametrize("splits", [100, 102, 105, 116])
 def test_gemm_split_k(splits):
     """Small output + long contraction: fp32 slabs per split + finishing pass (wgrad / lm_head dgrad)."""

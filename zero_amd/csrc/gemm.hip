@@ -194,6 +194,32 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, f32x4 (&acc)[TM][T
         *reinterpret_cast<f32x4*>(slab + (size_t)m * g.N + n + 4) = hi;
         continue;
       }
+      if (epi == ZK_EPI_SWIGLU_BWD) {
+        // v = dh for features n..n+7 (rounded to bf16 as the unfused path stores it); gate / up of
+        // the forward sit in the interleaved layout at column (n / 32) * 64 + n % 32 (+ 32)
+        const int col = ((n >> 5) << 6) + (n & 31);
+        const u32x4 gq = *reinterpret_cast<const u32x4*>(g.aux_in + (size_t)m * g.ldaux + col);
+        const u32x4 uq = *reinterpret_cast<const u32x4*>(g.aux_in + (size_t)m * g.ldaux + col + 32);
+        u32x4 og, ou;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float r0[2], r1[2];
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const float gg = hh ? hi_bf(gq[e]) : lo_bf(gq[e]);
+            const float uu = hh ? hi_bf(uq[e]) : lo_bf(uq[e]);
+            const float d = bf2f(f2bf(v[2 * e + hh]));
+            const float sg = 1.0f / (1.0f + __expf(-gg));
+            r0[hh] = d * uu * sg * (1.0f + gg * (1.0f - sg));
+            r1[hh] = d * (gg * sg);
+          }
+          og[e] = pack2bf(r0[0], r0[1]);
+          ou[e] = pack2bf(r1[0], r1[1]);
+        }
+        *reinterpret_cast<u32x4*>(g.C + (size_t)m * g.ldc + col) = og;
+        *reinterpret_cast<u32x4*>(g.C + (size_t)m * g.ldc + col + 32) = ou;
+        continue;
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha + bias[e];
       if (epi == ZK_EPI_QUICK_GELU || epi == ZK_EPI_GELU_ERF) {
@@ -230,6 +256,33 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, f32x4 (&acc)[TM][T
 #pragma unroll
       for (int e = 0; e < 4; ++e) out[e] = pack2bf(v[2 * e], v[2 * e + 1]);
       *reinterpret_cast<u32x4*>(cp) = out;
+    }
+    if constexpr (TN == 4) {
+      if (epi == ZK_EPI_SWIGLU) {
+        // second pass over the same patch: this wave's 64 columns are one interleave block
+        // [32 gate | 32 up]; 4 lanes per row, 8 features each: h = bf16(silu(gate)) * up
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int row = ps * 16 + (lane >> 2), c = lane & 3;
+          const int m = m0 + wm * (TM * 16) + p * 32 + row;
+          const int nb = n0 + wn * 64;
+          if (m >= g.M || nb >= g.N) continue;
+          const float* pr = wl + row * LD + c * 8;
+          u32x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float r[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const float gg = bf2f(f2bf(pr[2 * e + hh])), uu = bf2f(f2bf(pr[32 + 2 * e + hh]));
+              const float sl = gg / (1.0f + __expf(-gg));
+              r[hh] = bf2f(f2bf(sl)) * uu;      // tf:llama:175: act_fn(gate) is a bf16 tensor
+            }
+            o4[e] = pack2bf(r[0], r[1]);
+          }
+          *reinterpret_cast<u32x4*>(g.aux_out + (size_t)m * g.ldaux + (nb >> 1) + c * 8) = o4;
+        }
+      }
     }
   }
 }
@@ -653,11 +706,11 @@ void launch_cfg(const GemmArgs& g0, int transA, int transB, hipStream_t stream) 
 }
 
 // Tile choice: time ~ rounds(tiles / concurrent blocks) x tile area / relative efficiency.
-int choose_tile(int64_t M, int64_t N, int transA, int transB) {
+int choose_tile(int64_t M, int64_t N, int transA, int transB, bool need_tn4 = false) {
   const bool nt_ring = !transA && !transB && g_ring;
   if (g_force_tile >= 0) {
-    if (g_force_tile == 3 && transB) return 0;
-    if (g_force_tile == 4 && !nt_ring) return 2;
+    if (g_force_tile == 3 && (transB || need_tn4)) return 0;
+    if (g_force_tile == 4 && (!nt_ring || need_tn4)) return 2;
     return g_force_tile;
   }
   const int bm[5] = {128, 256, 256, 128, 384}, bn[5] = {128, 128, 256, 96, 192};
@@ -668,6 +721,7 @@ int choose_tile(int64_t M, int64_t N, int transA, int transB) {
   double best_cost = 1e300;
   for (int c = 0; c < 5; ++c) {
     if ((c == 3 && transB) || (c == 4 && !nt_ring)) continue;
+    if (need_tn4 && (c == 3 || c == 4)) continue;   // the SwiGLU epilogue needs 64 columns per wave
     double tiles = (double)((M + bm[c] - 1) / bm[c]) * (double)((N + bn[c] - 1) / bn[c]);
     double rounds = (double)(int64_t)((tiles + slots[c] - 1) / slots[c]);
     double cost = rounds * slots[c] * bm[c] * bn[c] / eff[c];
@@ -699,7 +753,12 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
   if ((!transA || !transB) && (K & 7)) return ZK_EINVAL;  // k-contiguous operands are read in 8-element chunks
   if (transA ? ((M & 7) || (lda & 7)) : (lda & 7)) return ZK_EINVAL;
   if (ldb & 7) return ZK_EINVAL;
-  if (epilogue < 0 || epilogue > ZK_EPI_MUL_DGELU_ERF) return ZK_EINVAL;
+  if (epilogue < 0 || epilogue > ZK_EPI_SWIGLU_BWD) return ZK_EINVAL;
+  if (epilogue == ZK_EPI_SWIGLU || epilogue == ZK_EPI_SWIGLU_BWD) {
+    if (bias || residual || accumulate || alpha_dev || alpha != 1.0f || (ldaux & 7)) return ZK_EINVAL;
+    if (epilogue == ZK_EPI_SWIGLU && (!aux_out || (N & 63) || ldaux < N / 2)) return ZK_EINVAL;
+    if (epilogue == ZK_EPI_SWIGLU_BWD && (!aux_in || (N & 31) || ldaux < 2 * N || ldc < 2 * N)) return ZK_EINVAL;
+  }
   if ((epilogue == ZK_EPI_MUL_DQUICK_GELU || epilogue == ZK_EPI_MUL_DGELU_ERF) && !aux_in) return ZK_EINVAL;
   if (residual && ((ldr & 7) || (reinterpret_cast<uintptr_t>(residual) & 15))) return ZK_EINVAL;
   if (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) return ZK_EINVAL;
@@ -742,11 +801,11 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
     ZK_CHECK_LAUNCH();
     return ZK_OK;
   }
-  switch (choose_tile(M, N, transA, transB)) {
+  const int tile = choose_tile(M, N, transA, transB, epilogue == ZK_EPI_SWIGLU);
+  switch (tile) {
     case 3: launch_cfg<128, 96, 2, 2>(g, transA, transB, stream); break;
     case 4:
     case 2: {
-      const int tile = choose_tile(M, N, transA, transB);
       if (!transA && !transB && g_ring) {
         GemmArgs gr = g;
         const int bm = tile == 4 ? 384 : 256, bn = tile == 4 ? 192 : 256;

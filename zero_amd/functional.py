@@ -65,6 +65,22 @@ def _frozen_t(w: torch.Tensor, owner: torch.Tensor) -> torch.Tensor:
     return wt
 
 
+def _frozen_gate_up(gw: torch.Tensor, uw: torch.Tensor):
+    """Resident copies for the fused SwiGLU of a FROZEN MLP: (interleaved [2F, d] weight, its transpose
+    [d, 2F] for the dgrad, down-projection helper not included).  Cached on the gate Parameter."""
+    cache = gw.__dict__.setdefault("_zk_gu", {})
+    hit = cache.get("gu")
+    if (hit is not None and hit[0] == (gw._version, uw._version) and hit[1] == (gw.data_ptr(), uw.data_ptr())):
+        return hit[2], hit[3]
+    wi = ops.interleave_gate_up(gw.detach(), uw.detach())
+    wit = wi.t().contiguous()
+    cache["gu"] = ((gw._version, uw._version), (gw.data_ptr(), uw.data_ptr()), wi, wit)
+    return wi, wit
+
+
+FUSE_SWIGLU = os.environ.get("ZERO_AMD_FUSE_SWIGLU", "1") != "0"
+
+
 def dgrad(dy2d: torch.Tensor, w: torch.Tensor, owner: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:
     """dx[M, in] = dy[M, out] @ W[out, in].  ``owner``: the Parameter whose storage ``w`` views."""
     owner = w if owner is None else owner
@@ -357,19 +373,26 @@ class DecoderLayerFn(torch.autograd.Function):
         xa = ops.gemm(ao, ow, residual=x2)
         h2, rstd2 = ops.rmsnorm_fwd(xa, l2w, eps, save_stats=need)
         F = gw.shape[0]
+        fused = (FUSE_SWIGLU and USE_TRANSPOSED_FROZEN and F % 32 == 0 and GradSink.slot(gw) is None
+                 and GradSink.slot(uw) is None and GradSink.slot(dw) is None)
         wgu = packed_rows(gw, uw)
-        if wgu is not None:
+        if fused:
+            # gate|up GEMM with the SwiGLU in its epilogue; gu is kept in the interleaved column order
+            gu, hm = ops.gemm_swiglu(h2, _frozen_gate_up(gw, uw)[0])
+        elif wgu is not None:
             gu = ops.gemm(h2, wgu)
+            hm = ops.swiglu_fwd(gu, F)
         else:
             gu = torch.empty((M, 2 * F), dtype=BF16, device=x.device)
             ops.gemm(h2, gw, out=gu[:, :F])
             ops.gemm(h2, uw, out=gu[:, F:])
-        hm = ops.swiglu_fwd(gu, F)
+            hm = ops.swiglu_fwd(gu, F)
         y = ops.gemm(hm, dw, residual=xa)
         if need:
             ctx.save_for_backward(x2, rstd1, qkv, ao, lse, xa, rstd2, gu, l1w, qw, kw, vw, ow, l2w, gw, uw, dw,
                                   cos_t, sin_t)
             ctx.dims = (B, S, d, nh, nkv, hd, F)
+            ctx.fused_swiglu = fused
         return y.view(B, S, d)
 
     @staticmethod
@@ -380,12 +403,17 @@ class DecoderLayerFn(torch.autograd.Function):
         dy2 = dy.reshape(M, d)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        d_hm = dgrad(dy2, dw)
-        d_gu = ops.swiglu_bwd(d_hm, gu, F)
         wgu = packed_rows(gw, uw)
-        if wgu is not None:
+        if ctx.fused_swiglu:
+            # dh = dy W_down with the SwiGLU backward in the epilogue (interleaved d_gate|d_up), then the
+            # dgrad through the interleaved gate|up weight (same K order on both operands)
+            d_gu = ops.gemm_swiglu_bwd(dy2, _frozen_t(dw, dw), gu)
+            d_h2 = ops.gemm(d_gu, _frozen_gate_up(gw, uw)[1])
+        elif wgu is not None:
+            d_gu = ops.swiglu_bwd(dgrad(dy2, dw), gu, F)
             d_h2 = dgrad(d_gu, wgu, owner=gw)
         else:
+            d_gu = ops.swiglu_bwd(dgrad(dy2, dw), gu, F)
             d_h2 = ops.gemm(d_gu[:, :F], gw, trans_b=True)
             ops.gemm(d_gu[:, F:], uw, trans_b=True, out=d_h2, accumulate=True)
         dxa = ops.rmsnorm_bwd(d_h2, xa, l2w, rstd2, dres=dy2)

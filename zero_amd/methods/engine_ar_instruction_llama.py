@@ -155,6 +155,7 @@ class _NanWatch:
 
     def __init__(self):
         self.pending = []      # (event, pinned flag)
+        self.free = []         # pinned one-byte flags ready for reuse (no per-step host allocation)
 
     def check_and_arm(self, loss, device, sync: bool = False):
         keep = []
@@ -164,17 +165,17 @@ class _NanWatch:
                     self.pending = []
                     rank = dist.get_rank() if dist.is_initialized() else 0
                     raise ValueError(f"loss is NaN on rank {rank}")
+                self.free.append((ev, flag))
             else:
                 keep.append((ev, flag))
-        self.pending = keep[-8:]
+        self.pending = keep
         if device.type != "cuda":
             if bool(loss.isnan()):
                 rank = dist.get_rank() if dist.is_initialized() else 0
                 raise ValueError(f"loss is NaN on rank {rank}")
             return
-        flag = torch.empty(1, dtype=torch.bool).pin_memory()
+        ev, flag = self.free.pop() if self.free else (torch.cuda.Event(), torch.empty(1, dtype=torch.bool).pin_memory())
         flag.copy_(loss.detach().isnan().reshape(1), non_blocking=True)
-        ev = torch.cuda.Event()
         ev.record()
         self.pending.append((ev, flag))
 

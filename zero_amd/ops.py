@@ -14,6 +14,7 @@ import torch
 from ._lib import check, lib
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_MUL_DQUICK_GELU, EPI_MUL_DGELU_ERF = 0, 1, 2, 3, 4
+EPI_SWIGLU, EPI_SWIGLU_BWD = 5, 6
 BF16 = torch.bfloat16
 
 
@@ -95,6 +96,48 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
                           _workspace(a.device).data_ptr(), WORKSPACE_BYTES, _stream())
     check(rc, f"zk_gemm_bf16 M={M} N={N} K={K} tA={trans_a} tB={trans_b}")
     return out
+
+
+def interleave_gate_up(gate_w: torch.Tensor, up_w: torch.Tensor) -> torch.Tensor:
+    """[2F, in] weight whose row blocks of 64 are [32 gate rows | the matching 32 up rows]: the layout
+    the fused SwiGLU epilogues expect (include/zero_hip.h, ZK_EPI_SWIGLU).  One-time preparation."""
+    F, K = gate_w.shape
+    if F % 32 or up_w.shape != gate_w.shape:
+        raise ValueError("interleave_gate_up: F must be a multiple of 32")
+    return torch.stack((gate_w.reshape(F // 32, 32, K), up_w.reshape(F // 32, 32, K)), dim=1).reshape(2 * F, K).contiguous()
+
+
+def gemm_swiglu(x: torch.Tensor, wgu_i: torch.Tensor):
+    """gu_i[M, 2F] = x @ wgu_i^T (interleaved gate|up, kept for backward) and h[M, F] = silu(gate) * up,
+    in one launch (ZK_EPI_SWIGLU)."""
+    _chk2d(x, "x"); _chk2d(wgu_i, "wgu_i")
+    M, K = x.shape
+    N = wgu_i.shape[0]
+    if wgu_i.shape[1] != K or N % 64:
+        raise ValueError("gemm_swiglu: shapes")
+    gu = torch.empty((M, N), dtype=BF16, device=x.device)
+    h = torch.empty((M, N // 2), dtype=BF16, device=x.device)
+    rc = lib.zk_gemm_bf16(_p(x), _p(wgu_i), _p(gu), M, N, K, x.stride(0), wgu_i.stride(0), gu.stride(0), 0, 0,
+                          EPI_SWIGLU, None, None, 0, _p(h), None, h.stride(0), 1.0, None, 0,
+                          _workspace(x.device).data_ptr(), WORKSPACE_BYTES, _stream())
+    check(rc, f"zk_gemm_bf16(SWIGLU) M={M} N={N} K={K}")
+    return gu, h
+
+
+def gemm_swiglu_bwd(dy: torch.Tensor, w_down_t: torch.Tensor, gu_i: torch.Tensor) -> torch.Tensor:
+    """d_gu_i[M, 2F] (interleaved) from dh = dy @ w_down_t^T (w_down_t: [F, d] = down_proj.weight^T) and the
+    saved interleaved gate|up, in one launch (ZK_EPI_SWIGLU_BWD)."""
+    _chk2d(dy, "dy"); _chk2d(w_down_t, "w_down_t"); _chk2d(gu_i, "gu_i")
+    M, K = dy.shape
+    F = w_down_t.shape[0]
+    if w_down_t.shape[1] != K or gu_i.shape != (M, 2 * F) or F % 32:
+        raise ValueError("gemm_swiglu_bwd: shapes")
+    dgu = torch.empty((M, 2 * F), dtype=BF16, device=dy.device)
+    rc = lib.zk_gemm_bf16(_p(dy), _p(w_down_t), _p(dgu), M, F, K, dy.stride(0), w_down_t.stride(0), dgu.stride(0), 0, 0,
+                          EPI_SWIGLU_BWD, None, None, 0, None, _p(gu_i), gu_i.stride(0), 1.0, None, 0,
+                          _workspace(dy.device).data_ptr(), WORKSPACE_BYTES, _stream())
+    check(rc, f"zk_gemm_bf16(SWIGLU_BWD) M={M} N={F} K={K}")
+    return dgu
 
 
 def attn_fwd(q, k, v, B: int, S: int, Hq: int, Hkv: int, hd: int, scale: float, causal: bool,
