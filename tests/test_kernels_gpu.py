@@ -148,6 +148,71 @@ def test_gemm_fused_swiglu_matches_unfused(M, F, K, gemm_tile):
     assert relerr(dx, dx_ref.float()) < 6e-3
 
 
+# (M, N, K): > 256 tiles so a persistent workgroup walks several tiles; ragged and exact edges; K >= 256
+PRING_SHAPES = [(4616, 4096, 320), (6144, 5120, 256), (4616, 3072, 1024), (5000, 4104, 264), (12288, 6144, 512)]
+
+
+@pytest.mark.parametrize("M,N,K", PRING_SHAPES)
+@pytest.mark.parametrize("tile", [2, 4], ids=["t256", "t384x192"])
+def test_gemm_persistent_ring(M, N, K, tile):
+    """Persistent slot-ring kernel (several tiles per workgroup, DMA stream across tile boundaries)
+    against the fp32 product, and BIT-equal to the one-workgroup-per-tile ring kernel."""
+    a, b = rnd(M, K, seed=51), rnd(N, K, seed=52, scale=0.5)
+    bias, res = rnd(N, seed=53), rnd(M, N, seed=54)
+    ops.set_gemm_tile(tile)
+    try:
+        outs = {}
+        for pr in (51, 50):
+            ops.set_gemm_tile(pr)
+            c0 = ops.gemm(a, b)
+            c1 = ops.gemm(a, b, bias=bias, residual=res)
+            aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            c2 = ops.gemm(a, b, bias=bias, epilogue=ops.EPI_QUICK_GELU, aux_out=aux)
+            c3 = ops.gemm(a, b, epilogue=ops.EPI_MUL_DGELU_ERF, aux_in=res, alpha=0.5)
+            c4 = ops.gemm(a, b, out=res.clone(), accumulate=True)
+            outs[pr] = (c0, c1, aux, c2, c3, c4)
+        ref = a.float() @ b.float().t()
+        assert relerr(outs[51][0], ref) < 6e-3
+        for x, y in zip(outs[51], outs[50]):
+            assert torch.equal(x, y)
+    finally:
+        ops.set_gemm_tile(51)
+        ops.set_gemm_tile(-1)
+
+
+def test_gemm_persistent_ring_repeatable():
+    """Same launch 20 times: a read that overtakes its DMA (or a slot refilled too early) shows up as
+    run-to-run differences; also against the fp32 product at the decoder's gate|up shape."""
+    M, N, K = 6144, 16384, 3072
+    a, b = rnd(M, K, seed=55), rnd(N, K, seed=56, scale=0.05)
+    first = ops.gemm(a, b)
+    ref = (a.float() @ b.float().t())
+    assert relerr(first, ref) < 6e-3
+    del ref
+    for _ in range(20):
+        assert torch.equal(ops.gemm(a, b), first)
+
+
+@pytest.mark.parametrize("M,F,K", [(4616, 2048, 320), (6144, 8192, 256)])
+def test_gemm_persistent_ring_swiglu(M, F, K):
+    """Fused SwiGLU epilogues on the persistent kernel: bit-identical to the separate kernels."""
+    x, gw, uw = rnd(M, K, seed=61), rnd(F, K, seed=62, scale=0.2), rnd(F, K, seed=63, scale=0.2)
+    wgu = torch.cat((gw, uw), 0)
+    gu_ref = ops.gemm(x, wgu)
+    h_ref = ops.swiglu_fwd(gu_ref, F)
+    wi = ops.interleave_gate_up(gw, uw)
+    gu_i, h = ops.gemm_swiglu(x, wi)
+    blk = gu_i.view(M, F // 32, 2, 32)
+    assert torch.equal(blk[:, :, 0].reshape(M, F), gu_ref[:, :F]) and torch.equal(blk[:, :, 1].reshape(M, F), gu_ref[:, F:])
+    assert torch.equal(h, h_ref)
+    D = 512
+    dy, wd = rnd(M, D, seed=64), rnd(D, F, seed=65, scale=0.2)
+    dgu_ref = ops.swiglu_bwd(ops.gemm(dy, wd, trans_b=True), gu_ref, F)
+    dgu_i = ops.gemm_swiglu_bwd(dy, wd.t().contiguous(), gu_i)
+    blk = dgu_i.view(M, F // 32, 2, 32)
+    assert torch.equal(blk[:, :, 0].reshape(M, F), dgu_ref[:, :F]) and torch.equal(blk[:, :, 1].reshape(M, F), dgu_ref[:, F:])
+
+
 @pytest.mark.parametrize("splits", [100, 102, 105, 116])
 def test_gemm_split_k(splits):
     """Small output + long contraction: fp32 slabs per split + finishing pass (wgrad / lm_head dgrad)."""

@@ -25,6 +25,11 @@ SHAPES = [  # (name, M, N, K, trans_a, trans_b)
     ("enc wg o   TN", 1024, 1024, 4616, True, True),
     ("lm head    NT", 1024, 128256, 3072, False, False),
     ("lm dgrad   NN", 1024, 3072, 128256, False, True),
+    ("square 4k  NT", 4096, 4096, 4096, False, False),
+    ("square 8k  NT", 8192, 8192, 8192, False, False),
+    ("c2 fc1     NT", 36928, 4096, 1024, False, False),
+    ("c2 fc2     NT", 36928, 1024, 4096, False, False),
+    ("c2 qkv     NT", 36928, 3072, 1024, False, False),
 ]
 
 
@@ -35,11 +40,12 @@ def main():
         b = torch.randn((k, n) if tb else (n, k), device="cuda").to(torch.bfloat16)
         out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
         line = f"{name}  M={m:6d} N={n:6d} K={k:6d} :"
-        for cfg, stg in ((0, 11), (1, 11), (2, 11), (3, 11), (4, 11), (-1, 11)):
-            if (stg == 22 or cfg == 4) and (ta or tb):
+        for cfg, stg, pr in ((0, 11, 1), (1, 11, 1), (2, 11, 0), (2, 11, 1), (3, 11, 1), (4, 11, 0), (4, 11, 1), (-1, 11, 1)):
+            if (stg == 22 or cfg == 4 or pr == 0) and (ta or tb):
                 continue
             ops.set_gemm_tile(21)
-            ops.set_gemm_tile(stg)          # 22 = older 256x256 ring kernel
+            ops.set_gemm_tile(stg)
+            ops.set_gemm_tile(50 + pr)      # 51 = persistent ring (default), 50 = one workgroup per tile
             ops.set_gemm_tile(cfg)
             for _ in range(3):
                 ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out)
@@ -51,7 +57,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / iters
-            line += f"  t{cfg:2d}{'o' if stg == 22 else 'r'}: {2.0 * m * n * k / ms / 1e9:7.1f} TF ({ms * 1e3:6.0f} us)"
+            line += f"  t{cfg:2d}{'p' if pr else 'r'}: {2.0 * m * n * k / ms / 1e9:7.1f} TF ({ms * 1e3:6.0f} us)"
         ops.set_gemm_tile(101)
         for _ in range(3):
             ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out)
@@ -68,6 +74,7 @@ def main():
     ops.set_gemm_tile(-1)
     ops.set_gemm_tile(11)
     ops.set_gemm_tile(21)
+    ops.set_gemm_tile(51)
 
 
 if __name__ == "__main__":

@@ -651,6 +651,325 @@ __global__ __launch_bounds__(512) void gemm_ringx_kernel(GemmArgs g) {
   store_tile<TM, TN>(g, acc, m0, n0, wm, wn, lane, 0, reinterpret_cast<float*>(smem + wave * kEpiPatchBytes));
 }
 
+// ------------------------------------------------------------------------------------------
+// Persistent NT slot ring ("pring"): the kernel for the large NT products.
+// Measured on the ringx kernel above (tools/ring_modes.py, 6144 x 16384 x 3072): of 95 us per
+// 256x256 tile, 66 us are the K loop, ~9 us the hand-over between two workgroups on a CU (LDS
+// release, dispatch, argument loads, the first DMA round trip with an empty ring) and 12-20 us the
+// epilogue, during which the CU's matrix pipes idle and 256 CUs write in the same few microseconds.
+// Here ONE workgroup per CU walks its tiles (id, id + grid, ...: the same XCD-aware order as before)
+// and the DMA ring never drains: slot loads form one stream over (tile, K-tile, part), so while the
+// last K-tiles of a tile are being multiplied the first K-tiles of the NEXT tile are already landing.
+// The epilogue uses a small dedicated LDS patch (2 KiB per wave, XOR-swizzled, 16 rows x 32 columns
+// per pass) instead of the ring's memory, and its global stores are fire-and-forget: the next
+// tile's first K-tile needs no vmcnt wait (its data was waited for BEFORE the first store), so the
+// stores drain behind the next tile's MFMAs.
+//   256x256: RS 128, 9 slots of 16 KiB (2.25 K-tiles) + 16 KiB patch = 160 KiB
+//   384x192: RS 192, 6 slots of 24 KiB (2 K-tiles)    + 16 KiB patch = 160 KiB, waves 4(M) x 2(N)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int patch_swz(int r) { return ((r >> 1) & 3) | ((r & 1) << 2); }
+
+// Epilogue of one wave's (TM*16) x (TN*16) sub-tile through its private 16 x 32 fp32 LDS patch.
+// Write side: lane (r = l & 15, g = l >> 4) owns C[r][4g..4g+3] of a 16x16 fragment; read side: lane
+// (row = l >> 2, q = l & 3) gets 8 consecutive columns of one row: a wave-instruction stores 16 rows
+// x 64 bytes.  Chunk c (16 bytes) of row r lives at chunk c ^ patch_swz(r): conflict-free both ways.
+// EPI selects the code that is compiled in: 0 = alpha / bias / residual / accumulate, 1 = the
+// quick-GELU pair (forward with pre-activation copy, backward multiply), 2 = the SwiGLU pair,
+// 3 = nothing (ablation).
+template <int TM, int TN, int WAITN, int EPI>
+__device__ __forceinline__ void store_tile_p(const GemmArgs& g, f32x4 (&acc)[TM][TN], int mw, int nw, int lane,
+                                             unsigned char* patch) {
+  static_assert(TN % 2 == 0, "two fragments per pass");
+  constexpr int NJ = TN / 2;
+  const int wr = lane & 15, wg = lane >> 4, rr = lane >> 2, rq = lane & 3;
+  unsigned char* wp0 = patch + wr * 128 + ((wg ^ patch_swz(wr)) << 4);
+  unsigned char* wp1 = patch + wr * 128 + (((4 + wg) ^ patch_swz(wr)) << 4);
+  const unsigned char* rp0 = patch + rr * 128 + (((2 * rq) ^ patch_swz(rr)) << 4);
+  const unsigned char* rp1 = patch + rr * 128 + (((2 * rq + 1) ^ patch_swz(rr)) << 4);
+  const int epi = g.epilogue;
+  float alpha = g.alpha;
+  if (g.alpha_dev) alpha *= *g.alpha_dev;
+  float bias[NJ][8];
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[jj][e] = 0.f;
+    const int n = nw + jj * 32 + rq * 8;
+    if (EPI < 2 && g.bias && n < g.N) {
+      const u32x4 b = *reinterpret_cast<const u32x4*>(g.bias + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bias[jj][2 * e] = lo_bf(b[e]); bias[jj][2 * e + 1] = hi_bf(b[e]); }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mw + i * 16 + rr;
+    float gate[8];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      *reinterpret_cast<f32x4*>(wp0) = acc[i][2 * jj];
+      *reinterpret_cast<f32x4*>(wp1) = acc[i][2 * jj + 1];
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(rp0);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(rp1);
+      // the next tile's second K-tile (issued before this point) has landed once at most WAITN DMA
+      // instructions are left: wait here, before the first store enters the (in-order) vmcnt queue
+      if (i == 0 && jj == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+      if (EPI == 3) {
+        if (lo[0] + hi[3] == 123.456f) g.C[0] = f2bf(lo[1]);
+        continue;
+      }
+      const int n = nw + jj * 32 + rq * 8;
+      const bool ok = m < g.M && n < g.N;
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (EPI == 2 && epi == ZK_EPI_SWIGLU_BWD) {
+        if (!ok) continue;
+        const int col = ((n >> 5) << 6) + (n & 31);
+        const u32x4 gq = *reinterpret_cast<const u32x4*>(g.aux_in + (size_t)m * g.ldaux + col);
+        const u32x4 uq = *reinterpret_cast<const u32x4*>(g.aux_in + (size_t)m * g.ldaux + col + 32);
+        u32x4 og, ou;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float r0[2], r1[2];
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const float gg = hh ? hi_bf(gq[e]) : lo_bf(gq[e]);
+            const float uu = hh ? hi_bf(uq[e]) : lo_bf(uq[e]);
+            const float d = bf2f(f2bf(v[2 * e + hh]));
+            const float sg = 1.0f / (1.0f + __expf(-gg));
+            r0[hh] = d * uu * sg * (1.0f + gg * (1.0f - sg));
+            r1[hh] = d * (gg * sg);
+          }
+          og[e] = pack2bf(r0[0], r0[1]);
+          ou[e] = pack2bf(r1[0], r1[1]);
+        }
+        *reinterpret_cast<u32x4*>(g.C + (size_t)m * g.ldc + col) = og;
+        *reinterpret_cast<u32x4*>(g.C + (size_t)m * g.ldc + col + 32) = ou;
+        continue;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha + bias[jj][e];
+      if (EPI == 1 && ok) {
+        if (epi == ZK_EPI_QUICK_GELU) {
+          u32x4 pre;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pre[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+          if (g.aux_out) *reinterpret_cast<u32x4*>(g.aux_out + (size_t)m * g.ldc + n) = pre;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] = act_quick_gelu(lo_bf(pre[e])); v[2 * e + 1] = act_quick_gelu(hi_bf(pre[e])); }
+        } else {
+          const u32x4 h = *reinterpret_cast<const u32x4*>(g.aux_in + (size_t)m * g.ldaux + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= dact_quick_gelu((e & 1) ? hi_bf(h[e >> 1]) : lo_bf(h[e >> 1]));
+        }
+      }
+      if (!ok) continue;
+      if (EPI < 2 && g.residual) {
+        // x = residual + bf16(f(x)) : the branch output is rounded before the add
+        const u32x4 r = *reinterpret_cast<const u32x4*>(g.residual + (size_t)m * g.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e])) + ((e & 1) ? hi_bf(r[e >> 1]) : lo_bf(r[e >> 1]));
+      }
+      bf16_t* cp = g.C + (size_t)m * g.ldc + n;
+      if (EPI < 2 && g.accumulate) {
+        const u32x4 o = *reinterpret_cast<const u32x4*>(cp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (e & 1) ? hi_bf(o[e >> 1]) : lo_bf(o[e >> 1]);
+      }
+      u32x4 out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+      *reinterpret_cast<u32x4*>(cp) = out;
+      if constexpr (TN == 4 && EPI == 2) {
+        // ZK_EPI_SWIGLU: this wave's 64 columns are one interleave block [32 gate | 32 up]: jj = 0
+        // delivered the lane's 8 gate features, jj = 1 the matching up features of the same row
+        if (jj == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { gate[2 * e] = lo_bf(out[e]); gate[2 * e + 1] = hi_bf(out[e]); }
+        } else {
+          u32x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float r[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const float gg = gate[2 * e + hh], uu = hh ? hi_bf(out[e]) : lo_bf(out[e]);
+              const float sl = gg / (1.0f + __expf(-gg));
+              r[hh] = bf2f(f2bf(sl)) * uu;      // tf:llama:175: act_fn(gate) is a bf16 tensor
+            }
+            o4[e] = pack2bf(r[0], r[1]);
+          }
+          *reinterpret_cast<u32x4*>(g.aux_out + (size_t)m * g.ldaux + (nw >> 1) + rq * 8) = o4;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int RS, int NSLOT, bool LEAN, int EPI>
+__global__ __launch_bounds__(512) void gemm_pring_kernel(GemmArgs g) {
+  constexpr int NT = 512;
+  static_assert(WAVES_M * WAVES_N == 8, "8 waves");
+  constexpr int TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
+  constexpr int SA = BM / RS, SB = BN / RS, SPT = SA + SB;
+  static_assert(SA * RS == BM && SB * RS == BN && NSLOT >= 2 * SPT && NSLOT - 2 * SPT < SPT, "slot geometry");
+  static_assert(RS % (TM * 16) == 0 && RS % (TN * 16) == 0, "a wave's rows lie in one slot");
+  constexpr int SLOT = RS * BK * 2;
+  constexpr int PER = RS * 8 / NT;             // DMA instructions per thread per slot
+  static_assert(PER * NT == RS * 8, "slot rows");
+  constexpr int AHEAD = NSLOT - 2 * SPT;       // slots that stay in flight when the next K-tile is needed
+  constexpr int WAITN = AHEAD * PER;
+  constexpr int PATCH = 2048;
+  static_assert(NSLOT * SLOT + 8 * PATCH <= 160 * 1024, "LDS budget");
+  static_assert((NSLOT - SPT) * PER <= 63, "prologue wait");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSLOT * SLOT + 8 * PATCH];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int G = gridDim.x;
+  const int n_my = (ntiles - (int)blockIdx.x + G - 1) / G;
+  const int nk = (g.K + BK - 1) / BK;
+
+  auto coords = [&](int ord, int& m0, int& n0) {   // (past the last tile: the last tile again, see below)
+    int id = blockIdx.x + (ord < n_my ? ord : n_my - 1) * G;
+    int q = ntiles >> 3, r = ntiles & 7, xcd = id & 7, idx = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int band = id / (8 * g.tiles_n);
+    const int band_m = min(8, g.tiles_m - band * 8);
+    const int within = id - band * 8 * g.tiles_n;
+    m0 = (band * 8 + within % band_m) * BM;
+    n0 = (within / band_m) * BN;
+  };
+
+  // whole-matrix descriptors; the tile origin goes into the (scalar) offset (host: M*lda, N*ldb < 2^30)
+  __amdgpu_buffer_rsrc_t rA = make_rsrc(g.A, 0x7FFFFFF0u);
+  __amdgpu_buffer_rsrc_t rB = make_rsrc(g.B, 0x7FFFFFF0u);
+  const unsigned voff_a = (unsigned)((tid >> 3) * g.lda + (((tid & 7) ^ ((tid >> 3) & 7)) * 8)) * 2u;
+  const unsigned voff_b = (unsigned)((tid >> 3) * g.ldb + (((tid & 7) ^ ((tid >> 3) & 7)) * 8)) * 2u;
+
+  // ---- issue side: a cursor over the stream of slot loads (tile, K-tile, part), all scalar and
+  // branch-free.  Past the end of the stream the cursor keeps re-reading the last tile into slots
+  // nobody reads again, so every step of every tile is the same straight-line code with the same
+  // vmcnt arithmetic (cost: NSLOT slot loads per workgroup, drained before the workgroup exits).
+  int i_tk = 0, i_pos = 0, i_m0, i_n0, nx_m0, nx_n0;
+  coords(0, i_m0, i_n0);
+  coords(1, nx_m0, nx_n0);
+  auto issue_part = [&](auto part_c) {
+    constexpr int part = decltype(part_c)::value;
+    constexpr bool is_a = part < SA;
+    constexpr int row0 = (is_a ? part : part - SA) * RS;
+    unsigned char* dst = smem + i_pos * SLOT;
+    const int ld = is_a ? g.lda : g.ldb;
+    const int base_row = (is_a ? i_m0 : i_n0) + row0;
+    if constexpr (LEAN) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        unsigned char* d = dst + (wv * 64 + NT * i) * 16;
+        const int soff = ((base_row + 64 * i) * ld + i_tk * BK) * 2;
+        if (is_a) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)d, 16, voff_a, soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)d, 16, voff_b, soff, 0, 0);
+      }
+    } else {
+      tile_dma<false, RS, NT>(is_a ? rA : rB, dst, ld, 0, is_a ? g.M : g.N, i_tk * BK, g.K, tid, base_row);
+    }
+    i_pos = (i_pos + 1 == NSLOT) ? 0 : i_pos + 1;
+    if constexpr (part == SPT - 1) {
+      const bool wrap = i_tk + 1 == nk;
+      i_tk = wrap ? 0 : i_tk + 1;
+      i_m0 = wrap ? nx_m0 : i_m0;
+      i_n0 = wrap ? nx_n0 : i_n0;
+    }
+  };
+  auto issue_group = [&](auto first_c, auto count_c) {
+    constexpr int FIRST = decltype(first_c)::value, COUNT = decltype(count_c)::value;
+    static_assert(COUNT <= 9, "unrolled by hand");
+    if constexpr (COUNT > 0) issue_part(std::integral_constant<int, (FIRST + 0) % SPT>{});
+    if constexpr (COUNT > 1) issue_part(std::integral_constant<int, (FIRST + 1) % SPT>{});
+    if constexpr (COUNT > 2) issue_part(std::integral_constant<int, (FIRST + 2) % SPT>{});
+    if constexpr (COUNT > 3) issue_part(std::integral_constant<int, (FIRST + 3) % SPT>{});
+    if constexpr (COUNT > 4) issue_part(std::integral_constant<int, (FIRST + 4) % SPT>{});
+    if constexpr (COUNT > 5) issue_part(std::integral_constant<int, (FIRST + 5) % SPT>{});
+    if constexpr (COUNT > 6) issue_part(std::integral_constant<int, (FIRST + 6) % SPT>{});
+    if constexpr (COUNT > 7) issue_part(std::integral_constant<int, (FIRST + 7) % SPT>{});
+    if constexpr (COUNT > 8) issue_part(std::integral_constant<int, (FIRST + 8) % SPT>{});
+  };
+  using T_ = std::true_type;
+  // prologue: fill the ring (host guarantees nk >= 4: no tile boundary in here), wait for K-tile 0
+  issue_group(std::integral_constant<int, 0>{}, std::integral_constant<int, NSLOT>{});
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - SPT) * PER) : "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- consume side
+  const int a_part = wm * (TM * 16) / RS, a_row = wm * (TM * 16) - a_part * RS;
+  const int b_part = SA + wn * (TN * 16) / RS, b_row = wn * (TN * 16) % RS;
+  int c_pos = 0;                                // ring position of part 0 of the K-tile being multiplied
+  auto slot_of = [&](int pos0, int part) {
+    int p = pos0 + part;
+    p = p >= NSLOT ? p - NSLOT : p;
+    return smem + p * SLOT;
+  };
+  f32x4 acc[TM][TN];
+  bf16x8 fa[TM], fb0[TN], fb1[TN];
+  // One k-half: MFMAs on (fa, fcur) while the fragments of the NEXT k-half arrive: B's into the
+  // other buffer up front, each A fragment in place as soon as its last MFMA has been issued.
+  auto burst = [&](bf16x8 (&fcur)[TN], bf16x8 (&fnext)[TN], const unsigned char* na, const unsigned char* nb, int nkk) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fnext[j] = frag_load<false, RS>(nb, b_row + j * 16, nkk, lane);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fcur[j], fa[i], acc[i][j], 0, 0, 0);
+      // (scheduling fence: keep the refill BEHIND the MFMAs that read the old value, or the
+      //  compiler hoists it into fresh registers and the kernel no longer fits 256 VGPRs)
+      __builtin_amdgcn_sched_barrier(0);
+      fa[i] = frag_load<false, RS>(na, a_row + i * 16, nkk, lane);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  {
+    const unsigned char* la = slot_of(0, a_part);
+    const unsigned char* lb = slot_of(0, b_part);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb0[j] = frag_load<false, RS>(lb, b_row + j * 16, 0, lane);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = frag_load<false, RS>(la, a_row + i * 16, 0, lane);
+  }
+
+  for (int ord = 0; ord < n_my; ++ord) {
+    int m0, n0;
+    coords(ord, m0, n0);
+    coords(ord + 1, nx_m0, nx_n0);              // the issue cursor crosses into the next tile at t = nk - 3
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // In a continued tile K-tile 1 was waited for before the previous epilogue's stores: its first
+    // step must not wait on vmcnt (the stores are still draining behind the MFMAs).
+    bool skip_vm = ord > 0;
+    for (int t = 0; t < nk; ++t) {
+      int npos = c_pos + SPT;
+      npos = npos >= NSLOT ? npos - NSLOT : npos;
+      burst(fb0, fb1, slot_of(c_pos, a_part), slot_of(c_pos, b_part), 1);
+      // the next K-tile of the stream must have landed, and every wave must hold its last
+      // fragments of this one before its slots are refilled
+      if (skip_vm) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAITN) : "memory");
+      skip_vm = false;
+      __builtin_amdgcn_s_barrier();
+      issue_group(std::integral_constant<int, NSLOT % SPT>{}, std::integral_constant<int, SPT>{});
+      // (for t = nk - 1 the fragments fetched here are K-tile 0 of the next tile)
+      burst(fb1, fb0, slot_of(npos, a_part), slot_of(npos, b_part), 0);
+      c_pos = npos;
+    }
+    store_tile_p<TM, TN, WAITN, EPI>(g, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), lane,
+                                     smem + NSLOT * SLOT + wv * PATCH);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+}
+
 // C = bf16(alpha * sum_s slab[s] (+ C)), 4 columns per thread
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* slab, bf16_t* C, int M, int N, int ldc,
                                                             int splits, float alpha, const float* alpha_dev,
@@ -680,12 +999,26 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* slab, b
 
 }  // namespace
 
+#ifndef ZK_KERNEL_PROBE   // (probe builds instantiate one kernel for disassembly: tools/probe_kernel.sh)
 namespace {
 int g_force_tile = -1;   // tuning hook: -1 = cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256
 int g_force_splits = 0;  // tuning hook: 0 = heuristic, 1 = never split K, n > 1 = force n splits
 int g_lean = 1;          // experiment hook: 0 = never use the lean DMA path
 int g_ring_mode = 0;     // experiment hook: 1 = ring kernel without MFMAs, 2 = without DMA (wrong results)
 int g_ring = 1;          // tuning hook: 1 = 3-stage ring kernel for NT products on the 256x128 tile
+int g_pring = 1;         // tuning hook: 1 = persistent slot ring for the large NT products (0 = one workgroup per tile)
+int g_num_cu[16] = {0};
+
+int num_cus() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (!g_num_cu[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    g_num_cu[dev] = n;
+  }
+  return g_num_cu[dev];
+}
 int g_stage_mode = 1;    // tuning hook: 0 = LDS-DMA for every operand, 1 = registers for transposed operands
 
 template <int BM, int BN, int WM_, int WN_>
@@ -737,6 +1070,7 @@ extern "C" int zk_gemm_set_tile(int cfg) {
   if (cfg == 20 || cfg == 21) { g_ring = cfg - 20; return ZK_OK; }
   if (cfg >= 30 && cfg <= 33) { g_ring_mode = cfg - 30; return ZK_OK; }
   if (cfg == 40 || cfg == 41) { g_lean = cfg - 40; return ZK_OK; }
+  if (cfg == 50 || cfg == 51) { g_pring = cfg - 50; return ZK_OK; }
   if (cfg >= 100 && cfg <= 116) { g_force_splits = cfg - 100; return ZK_OK; }   // 100 = heuristic, 101 = off
   if (cfg < -1 || cfg > 4) return ZK_EINVAL;
   g_force_tile = cfg;
@@ -812,6 +1146,31 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
         gr.tiles_m = (g.M + bm - 1) / bm; gr.tiles_n = (g.N + bn - 1) / bn;
         const dim3 rg(gr.tiles_m * gr.tiles_n);
         const bool lean = g.M % bm == 0 && g.N % bn == 0 && g.K % BK == 0 && g_lean;
+        // persistent ring: needs >= 4 K-tiles per tile and whole-matrix 32-bit byte offsets; the
+        // erf-GELU epilogues (adapter only) stay on the one-tile-per-workgroup kernel
+        const int pclass = g_ring_mode == 3 ? 3
+                           : epilogue == ZK_EPI_NONE ? 0
+                           : (epilogue == ZK_EPI_QUICK_GELU || epilogue == ZK_EPI_MUL_DQUICK_GELU) ? 1
+                           : (epilogue == ZK_EPI_SWIGLU || epilogue == ZK_EPI_SWIGLU_BWD) ? 2 : -1;
+        if (g_pring && pclass >= 0 && (g.K + BK - 1) / BK >= 4 && (M + 64) * lda * 2 < 0x7FFFFFF0LL &&
+            (N + 64) * ldb * 2 < 0x7FFFFFF0LL && (g_ring_mode == 0 || g_ring_mode == 3)) {
+          const int ncu = num_cus();
+          const int ntl = gr.tiles_m * gr.tiles_n;
+          const dim3 pg(ntl < ncu ? ntl : ncu);
+#define ZK_PRING(EPI_) \
+  do { \
+    if (tile == 4 && lean) hipLaunchKernelGGL((gemm_pring_kernel<384, 192, 4, 2, 192, 6, true, EPI_>), pg, dim3(512), 0, stream, gr); \
+    else if (tile == 4) hipLaunchKernelGGL((gemm_pring_kernel<384, 192, 4, 2, 192, 6, false, EPI_>), pg, dim3(512), 0, stream, gr); \
+    else if (lean) hipLaunchKernelGGL((gemm_pring_kernel<256, 256, 2, 4, 128, 9, true, EPI_>), pg, dim3(512), 0, stream, gr); \
+    else hipLaunchKernelGGL((gemm_pring_kernel<256, 256, 2, 4, 128, 9, false, EPI_>), pg, dim3(512), 0, stream, gr); \
+  } while (0)
+          if (pclass == 0) ZK_PRING(0);
+          else if (pclass == 1) ZK_PRING(1);
+          else if (pclass == 2) ZK_PRING(2);
+          else ZK_PRING(3);
+#undef ZK_PRING
+          break;
+        }
 #define ZK_RINGX(MODE_) \
   do { \
     if (tile == 4 && lean) hipLaunchKernelGGL((gemm_ringx_kernel<384, 192, 2, 4, 192, 6, MODE_, true>), rg, dim3(512), 0, stream, gr); \
@@ -846,3 +1205,4 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
   ZK_CHECK_LAUNCH();
   return ZK_OK;
 }
+#endif  // ZK_KERNEL_PROBE
