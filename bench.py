@@ -61,6 +61,37 @@ def flops_per_image(enc_layers, ft_after, d, nh, nkv, f, Ld, V, S, T=577, D=1024
     return total
 
 
+_TILES = {0: "128,128", 1: "256,128", 2: "256,256", 3: "128,96", 4: "384,192"}
+
+
+def plan_name(plan: int) -> str:
+    """zk_gemm_last_plan code -> the kernel symbol prefix rocprofv3 prints."""
+    kind, tile, lean, epi = plan // 1000, plan // 100 % 10, plan // 10 % 10, plan % 10
+    if kind == 4:
+        return f"gemm_kernel<128,128> split-K x{plan - 4000} + splitk_finish_kernel"
+    t = _TILES.get(tile, "?")
+    if kind == 3:
+        return f"gemm_pring_kernel<{t},lean={lean},epi={epi}>"
+    if kind == 2:
+        return f"gemm_ringx_kernel<{t},lean={lean}>"
+    if kind == 1:
+        return f"gemm_ring_kernel<{t}>"
+    return f"gemm_kernel<{t}>"
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes over this same
+    command (profiles/r01_pmc_summary.json, written by tools/pmc_bench.sh + tools/pmc_summary.py:
+    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None if no summary is present."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        with open(path) as f:
+            ent = json.load(f)["kernels"].get(kernel)
+        return ent and ent["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -181,53 +212,63 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     images_per_s = B * world * args.steps / dt
 
-    # ---- per-kernel timing of the GEMM family, live, with HIP events on the launch stream
+    # ---- per-kernel timing of the GEMMs, live, with HIP events on the launch stream.  Every
+    # zk_gemm_bf16 call (plain and fused) is bracketed by two events and attributed to the kernel
+    # variant the library launched (zk_gemm_last_plan), so each group below is ONE kernel symbol of
+    # the rocprofv3 table; the roofline line is the symbol with the largest total time.
     roofline = None
     if rank == 0 and not args.no_kernel_timing:
         records = []
-        real_gemm = ops.gemm
 
-        def timed_gemm(a, b, *, trans_a=False, trans_b=False, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = real_gemm(a, b, trans_a=trans_a, trans_b=trans_b, **kw)
-            e1.record()
-            M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
-            N = b.shape[1] if trans_b else b.shape[0]
-            records.append(((trans_a, trans_b), 2.0 * M * N * K, e0, e1, (M, N, K)))
-            return out
-        ops.gemm = timed_gemm
+        class _TimedLib:
+            def __init__(self, real):
+                self._real = real
+
+            def __getattr__(self, name):
+                return getattr(self._real, name)
+
+            def zk_gemm_bf16(self, A, Bp, C, M, N, K, lda, ldb, ldc, ta, tb, epi, *rest):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = self._real.zk_gemm_bf16(A, Bp, C, M, N, K, lda, ldb, ldc, ta, tb, epi, *rest)
+                e1.record()
+                records.append((self._real.zk_gemm_last_plan(), (ta, tb), 2.0 * M * N * K, e0, e1, (M, N, K), epi))
+                return rc
+
+        real_lib = ops.lib
+        ops.lib = _TimedLib(real_lib)
         try:
             for _ in range(2):
                 step()
             torch.cuda.synchronize()
         finally:
-            ops.gemm = real_gemm
-        fam = {}
-        for key, fl, e0, e1, shp in records:
-            d = fam.setdefault(key, dict(n=0, ms=0.0, flops=0.0))
-            d["n"] += 1; d["ms"] += e0.elapsed_time(e1); d["flops"] += fl
+            ops.lib = real_lib
+        fam, shp = {}, {}
+        for plan, tt, fl, e0, e1, mnk, epi in records:
+            ms = e0.elapsed_time(e1)
+            d = fam.setdefault(plan, dict(n=0, ms=0.0, flops=0.0))
+            d["n"] += 1; d["ms"] += ms; d["flops"] += fl
+            d_ = shp.setdefault((plan, tt, mnk, epi), [0, 0.0, fl])
+            d_[0] += 1; d_[1] += ms
         if args.gemm_shapes:
-            shp = {}
-            for k_, fl, e0, e1, mnk in records:
-                d_ = shp.setdefault((k_, mnk), [0, 0.0, fl])
-                d_[0] += 1; d_[1] += e0.elapsed_time(e1)
-            for (k_, mnk), (n_, ms_, fl) in sorted(shp.items(), key=lambda kv: -kv[1][1]):
-                print(f"  tA{int(k_[0])}tB{int(k_[1])} M,N,K={mnk}  x{n_ // 2:3d}/step  {ms_ / 2:7.2f} ms/step  "
-                      f"{fl * n_ / (ms_ * 1e-3) / 1e12:7.1f} TF/s", file=sys.stderr)
+            for (plan, tt, mnk, epi), (n_, ms_, fl) in sorted(shp.items(), key=lambda kv: -kv[1][1]):
+                print(f"  {plan_name(plan):46s} tA{tt[0]}tB{tt[1]} epi{epi} M,N,K={mnk}  x{n_ // 2:3d}/step  "
+                      f"{ms_ / 2:7.2f} ms/step  {fl * n_ / (ms_ * 1e-3) / 1e12:7.1f} TF/s", file=sys.stderr)
         key = max(fam, key=lambda k: fam[k]["ms"])
         d = fam[key]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        all_ms = sum(v["ms"] for v in fam.values())
+        all_fl = sum(v["flops"] for v in fam.values())
         roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                    "kernel": ("NT GEMM family: gemm_ringx_kernel<256,256|384,192> + gemm_kernel small tiles"
-                               if key == (False, False) else f"gemm_kernel<transA={int(key[0])},transB={int(key[1])}>"),
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(plan_name(key)),
+                    "kernel": plan_name(key),
                     "launches_per_step": d["n"] // 2, "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 1),
                     "avg_gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 1),
-                    "gemm_ms_per_step": round(sum(v["ms"] for v in fam.values()) / 2, 2),
-                    "families": {f"tA{int(k[0])}tB{int(k[1])}": {"n": v["n"] // 2, "ms": round(v["ms"] / 2, 2),
-                                                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
-                                 for k, v in fam.items()}}
+                    "gemm_ms_per_step": round(all_ms / 2, 2),
+                    "all_gemm_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1),
+                    "kernels": {plan_name(k): {"n": v["n"] // 2, "ms": round(v["ms"] / 2, 2),
+                                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                                for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}}
 
     # ---- CPU baseline: the oracle on the host cores, rank 0, N = 1 only, bounded sample
     cpu_baseline = None

@@ -74,8 +74,19 @@ int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, in
 /* Tuning hook (no counterpart in the reference): force the block tile of zk_gemm_bf16.
  * -1 = built-in cost model (default), 0 = 128x128, 1 = 256x128, 2 = 256x256;
  * 10/11 = LDS-DMA for all operands / registers for transposed ones (default);
+ * 20/21 = 256x128 ring kernel off/on, 40/41 = lean DMA addressing off/on,
+ * 50/51 = persistent slot ring off/on (default on: one workgroup per CU walks its tiles),
+ * 60 + b = m-tiles per band of its tile order (60 = default), 100000 + t = its start stagger in
+ * 10 ns ticks per phase step (99999 = built-in policy),
  * 100 = split-K heuristic (default), 101 = no split-K, 102..116 = force that many splits. */
 int zk_gemm_set_tile(int cfg);
+
+/* Measurement hook (no counterpart in the reference): which kernel variant this thread's last
+ * zk_gemm_bf16 call launched, so a benchmark can attribute its event timings to the kernel symbols a
+ * profiler reports.  kind * 1000 + tile * 100 + lean * 10 + epilogue class; kind 0 = two-stage
+ * gemm_kernel, 1 = gemm_ring_kernel, 2 = gemm_ringx_kernel, 3 = gemm_pring_kernel (persistent),
+ * 4 = split-K (4000 + splits); tile 0..4 = 128x128, 256x128, 256x256, 128x96, 384x192. */
+int zk_gemm_last_plan(void);
 
 /* ---- fused attention ----------------------------------------------------------------
  * softmax(Q K^T * scale [+ causal mask]) V, flash-style (no S x S matrix in HBM).

@@ -49,6 +49,8 @@ struct GemmArgs {
   int epilogue;
   int accumulate;  // C += result
   int tiles_m, tiles_n;
+  int band;                // m-tiles per band of the tile order (persistent ring kernel)
+  int phase_delay;         // experiment: start delay (in 10 ns ticks) per phase step of the persistent kernel
   int splits, kchunk;      // split-K: block (tile, s) covers k in [s*kchunk, min(K, (s+1)*kchunk))
   float* slab;             // [splits][M][N] fp32 partial results (split-K only)
 };
@@ -835,13 +837,19 @@ __global__ __launch_bounds__(512) void gemm_pring_kernel(GemmArgs g) {
     int id = blockIdx.x + (ord < n_my ? ord : n_my - 1) * G;
     int q = ntiles >> 3, r = ntiles & 7, xcd = id & 7, idx = id >> 3;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int band = id / (8 * g.tiles_n);
-    const int band_m = min(8, g.tiles_m - band * 8);
-    const int within = id - band * 8 * g.tiles_n;
-    m0 = (band * 8 + within % band_m) * BM;
+    const int band = id / (g.band * g.tiles_n);
+    const int band_m = min(g.band, g.tiles_m - band * g.band);
+    const int within = id - band * g.band * g.tiles_n;
+    m0 = (band * g.band + within % band_m) * BM;
     n0 = (within / band_m) * BN;
   };
 
+  if (g.phase_delay > 0) {   // start stagger (host policy in zk_gemm_bf16): the XCD's workgroups in 4 phases
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const int nph = g.phase_delay >> 20 ? g.phase_delay >> 20 : 4;
+    const unsigned long long wait = (unsigned long long)(g.phase_delay & 0xFFFFF) * ((blockIdx.x >> 3) % nph);
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
   // whole-matrix descriptors; the tile origin goes into the (scalar) offset (host: M*lda, N*ldb < 2^30)
   __amdgpu_buffer_rsrc_t rA = make_rsrc(g.A, 0x7FFFFFF0u);
   __amdgpu_buffer_rsrc_t rB = make_rsrc(g.B, 0x7FFFFFF0u);
@@ -1006,8 +1014,11 @@ int g_force_splits = 0;  // tuning hook: 0 = heuristic, 1 = never split K, n > 1
 int g_lean = 1;          // experiment hook: 0 = never use the lean DMA path
 int g_ring_mode = 0;     // experiment hook: 1 = ring kernel without MFMAs, 2 = without DMA (wrong results)
 int g_ring = 1;          // tuning hook: 1 = 3-stage ring kernel for NT products on the 256x128 tile
+int g_phase_delay = -1;  // tuning hook: persistent kernel start stagger, 10 ns ticks per phase step (-1 = policy below)
+int g_band = 0;          // tuning hook: m-tiles per band of the persistent kernel's tile order (0 = default)
 int g_pring = 1;         // tuning hook: 1 = persistent slot ring for the large NT products (0 = one workgroup per tile)
 int g_num_cu[16] = {0};
+thread_local int g_last_plan = -1;   // kernel variant of this thread's last zk_gemm_bf16 call (zk_gemm_last_plan)
 
 int num_cus() {
   int dev = 0;
@@ -1064,6 +1075,8 @@ int choose_tile(int64_t M, int64_t N, int transA, int transB, bool need_tn4 = fa
 }
 }  // namespace
 
+extern "C" int zk_gemm_last_plan(void) { return g_last_plan; }
+
 extern "C" int zk_gemm_set_tile(int cfg) {
   // cfg in [-1, 2] selects the tile; cfg = 10 / 11 selects the staging mode (0 / 1)
   if (cfg == 10 || cfg == 11) { g_stage_mode = cfg - 10; return ZK_OK; }
@@ -1071,6 +1084,9 @@ extern "C" int zk_gemm_set_tile(int cfg) {
   if (cfg >= 30 && cfg <= 33) { g_ring_mode = cfg - 30; return ZK_OK; }
   if (cfg == 40 || cfg == 41) { g_lean = cfg - 40; return ZK_OK; }
   if (cfg == 50 || cfg == 51) { g_pring = cfg - 50; return ZK_OK; }
+  if (cfg >= 60 && cfg <= 76) { g_band = cfg - 60; return ZK_OK; }   // 60 = default
+  if (cfg >= 100000) { g_phase_delay = cfg - 100000; return ZK_OK; }    // start stagger in 10 ns ticks (+ phases << 20)
+  if (cfg == 99999) { g_phase_delay = -1; return ZK_OK; }               // back to the built-in policy
   if (cfg >= 100 && cfg <= 116) { g_force_splits = cfg - 100; return ZK_OK; }   // 100 = heuristic, 101 = off
   if (cfg < -1 || cfg > 4) return ZK_EINVAL;
   g_force_tile = cfg;
@@ -1111,6 +1127,8 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
   g.lda = (int)lda; g.ldb = (int)ldb; g.ldc = (int)ldc; g.ldr = (int)ldr; g.ldaux = (int)ldaux;
   g.epilogue = epilogue; g.accumulate = accumulate;
   g.tiles_m = g.tiles_n = 0;
+  g.band = 8;
+  g.phase_delay = 0;
   g.splits = 1; g.kchunk = (int)((K + BK - 1) / BK * BK); g.slab = nullptr;
   // split-K for small outputs with a long contraction (wgrad, lm_head dgrad): fill the 256 CUs
   const bool plain = epilogue == ZK_EPI_NONE && !bias && !residual && !aux_out;
@@ -1127,6 +1145,7 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
     }
   }
   if (g.splits > 1) {
+    g_last_plan = 4000 + g.splits;
     launch_cfg<128, 128, 2, 2>(g, transA, transB, stream);
     int64_t nb = (M * (N / 4) + 255) / 256;
     if (nb > 2048) nb = 2048;
@@ -1136,6 +1155,7 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
     return ZK_OK;
   }
   const int tile = choose_tile(M, N, transA, transB, epilogue == ZK_EPI_SWIGLU);
+  g_last_plan = tile * 100;            // plain two-stage kernel unless a ring variant takes over below
   switch (tile) {
     case 3: launch_cfg<128, 96, 2, 2>(g, transA, transB, stream); break;
     case 4:
@@ -1157,6 +1177,17 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
           const int ncu = num_cus();
           const int ntl = gr.tiles_m * gr.tiles_n;
           const dim3 pg(ntl < ncu ? ntl : ncu);
+          g_last_plan = 3000 + tile * 100 + (lean ? 10 : 0) + pclass;
+          // an XCD holds 32 consecutive tiles of the order = band x (32 / band): its L2 then streams
+          // band * BM rows of A and (32 / band) * BN rows of B per K-tile; 384x192 tiles want 4 x 8
+          gr.band = g_band > 0 ? g_band : (tile == 4 ? 4 : 8);
+          // Start stagger.  Identical workgroups reach their epilogues together, and 256 CUs storing
+          // 128-256 KiB each within the same few microseconds run into the fabric's write rate (the
+          // stores block at issue, the matrix pipes idle).  Starting the 32 workgroups of an XCD in 4
+          // phases 3 us apart spreads every later tile boundary; measured (tools/bench_phase.py): fused
+          // gate|up 589 -> 501 us, fused down-dgrad 316 -> 294, lm_head 710 -> 684, C2 fc1 437 -> 412;
+          // with fewer than 3 tiles per workgroup the 9 us tail is not earned back.
+          gr.phase_delay = g_phase_delay >= 0 ? g_phase_delay : (ntl >= 3 * ncu ? 300 : 0);
 #define ZK_PRING(EPI_) \
   do { \
     if (tile == 4 && lean) hipLaunchKernelGGL((gemm_pring_kernel<384, 192, 4, 2, 192, 6, true, EPI_>), pg, dim3(512), 0, stream, gr); \
@@ -1171,6 +1202,7 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
 #undef ZK_PRING
           break;
         }
+        g_last_plan = 2000 + tile * 100 + (lean ? 10 : 0);
 #define ZK_RINGX(MODE_) \
   do { \
     if (tile == 4 && lean) hipLaunchKernelGGL((gemm_ringx_kernel<384, 192, 2, 4, 192, 6, MODE_, true>), rg, dim3(512), 0, stream, gr); \
@@ -1193,6 +1225,7 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
         GemmArgs gr = g;
         gr.tiles_m = (g.M + 255) / 256; gr.tiles_n = (g.N + 127) / 128;
         const dim3 rg(gr.tiles_m * gr.tiles_n);
+        g_last_plan = 1000 + tile * 100;
         if (g_ring_mode == 1) hipLaunchKernelGGL((gemm_ring_kernel<256, 128, 4, 2, 3, 1>), rg, dim3(512), 0, stream, gr);
         else if (g_ring_mode == 2) hipLaunchKernelGGL((gemm_ring_kernel<256, 128, 4, 2, 3, 2>), rg, dim3(512), 0, stream, gr);
         else hipLaunchKernelGGL((gemm_ring_kernel<256, 128, 4, 2, 3>), rg, dim3(512), 0, stream, gr);
