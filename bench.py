@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 8; 64 for c2)")
+    ap.add_argument("--stage", default="finetune-encoder", choices=["finetune-encoder", "pretrain"],
+                    help="training stage of ref:configs/zero/train_llama.py (pretrain = adapter + translator layer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--gemm-shapes", action="store_true", help="per-shape GEMM table on stderr")
@@ -44,7 +46,7 @@ def parse():
 
 
 def flops_per_image(enc_layers, ft_after, d, nh, nkv, f, Ld, V, S, T=577, D=1024, F=4096, H=16, n_valid=128,
-                    full_lm_head=True):
+                    full_lm_head=True, stage="finetune-encoder", n_translators=1):
     """SURVEY.md §8a counting rules: linear 2MKN; attention fwd 4 T^2 H hd (x1/2 causal);
     trainable bwd 2x fwd; frozen bwd 1x (GEMM) / 2x (attention)."""
     enc_layer = 2 * T * (4 * D * D + 2 * D * F) + 4 * T * T * D
@@ -57,7 +59,11 @@ def flops_per_image(enc_layers, ft_after, d, nh, nkv, f, Ld, V, S, T=577, D=1024
     dec_attn = 4 * S * S * nh * hd * 0.5
     rows = S if full_lm_head else n_valid
     lm = 2 * rows * d * V
+    if stage == "pretrain":        # no encoder backward; weight gradients of the translator layer(s)
+        enc_bwd = 0
     total = enc_fwd + enc_bwd + 3 * adapter + Ld * (2 * dec_gemm + 3 * dec_attn) + 2 * lm
+    if stage == "pretrain":
+        total += n_translators * dec_gemm
     return total
 
 
@@ -128,6 +134,7 @@ def main():
         cfg.translators_range = LLAMA_SHAPES[("3.1", "8")]["translators_range"]
     B = args.batch or (64 if args.workload == "c2" else 8)
     cfg.batch_size = B
+    cfg.training_stage = args.stage
     if os.environ.get("ZERO_AMD_NAN_CHECK"):      # A/B hook: "sync" = the reference's blocking check
         cfg.check_nan_loss = os.environ["ZERO_AMD_NAN_CHECK"]
 
@@ -287,20 +294,25 @@ def main():
         r = zo.train_step(sd, ecfg, odec, [imgs_cpu[0].to(torch.bfloat16).float()], ids[:1], tgts[:1], img_id=img_id,
                           pad_id=pad_id, encoder_ft_layers_after=cfg.encoder_ft_layers_after)
         cdt = time.perf_counter() - t0
+        # full-size parity spot check: the HIP path's loss on the SAME image with the SAME (current) weights
+        with torch.no_grad():
+            gl = float(forward_from_ids.__get__(model, model.__class__)(cfg, imgs[:1], ids[:1], tgts[:1], img_id, pad_id))
         cpu_baseline = {"value": round(1.0 / cdt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
                         "sample": f"1 image (S={S}) of the same workload: one fp32 forward+backward of the oracle "
                                   f"(oracle/zero_oracle.py) in {cdt:.1f} s, optimizer excluded",
-                        "loss": round(float(r.loss), 4)}
+                        "loss": round(float(r.loss), 4), "hip_loss_same_image": round(gl, 4),
+                        "loss_abs_diff": round(abs(gl - float(r.loss)), 5)}
 
     if rank == 0:
         dc = model.decoder.config if decoder is not None else None
         if dc is not None:
             Ld = len(model.decoder.model.layers)
             fl_alg = flops_per_image(24, cfg.encoder_ft_layers_after, dc.hidden_size, dc.num_attention_heads,
-                                     dc.num_key_value_heads, dc.intermediate_size, Ld, dc.vocab_size, S)
+                                     dc.num_key_value_heads, dc.intermediate_size, Ld, dc.vocab_size, S,
+                                     stage=args.stage)
             fl_exec = flops_per_image(24, cfg.encoder_ft_layers_after, dc.hidden_size, dc.num_attention_heads,
                                       dc.num_key_value_heads, dc.intermediate_size, Ld, dc.vocab_size, S,
-                                      n_valid=n_resp, full_lm_head=False)
+                                      n_valid=n_resp, full_lm_head=False, stage=args.stage)
         else:
             fl_alg = fl_exec = 0.680e12
         per_gpu = images_per_s / world
@@ -309,12 +321,16 @@ def main():
             "value": round(images_per_s, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": {"c3": "Llama-3.2-3B surrogate (18 layers) encoder-training step, encoder "
-                                           "layers 16-23 + adapter trainable, surrogate frozen",
+            "config": {"workload": {"c3": ("Llama-3.2-3B surrogate (18 layers) encoder-training step, encoder "
+                                            "layers 16-23 + adapter trainable, surrogate frozen"
+                                            if args.stage == "finetune-encoder" else
+                                            "Llama-3.2-3B surrogate (18 layers) stage-1 pretrain step: adapter + "
+                                            "post_layernorm + translator layer 16 trainable, encoder frozen"),
                                     "c4": "Llama-3.1-8B surrogate (19 layers) encoder-training step",
                                     "c2": "ViT-L/14-336 encoder + adapter forward/backward"}[args.workload],
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": S, "image": "336x336",
-                       "parallelism": f"dp{world}", "grad_accum": 1, "weights": "seeded random init"},
+                       "parallelism": f"dp{world}", "grad_accum": 1, "weights": "seeded random init",
+                       "stage": args.stage},
             "loss": round(float(loss), 4),
             "tflop_per_image_algorithmic": round(fl_alg / 1e12, 3),
             "tflop_per_image_executed": round(fl_exec / 1e12, 3),

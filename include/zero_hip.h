@@ -120,12 +120,17 @@ int zk_layernorm_bwd(const void* dy, const void* x, const void* gamma, const flo
                      int64_t rows, int64_t D, hipStream_t stream);
 
 /* ---- RMSNorm (tf:llama:62-67) ----------------------------------------------------------
- * y = w * bf16(x * rsqrt(mean(x^2) + eps)); bwd gives dx = dres + RMS'(dy) (w frozen).
+ * y = w * bf16(x * rsqrt(mean(x^2) + eps)); bwd gives dx = dres + RMS'(dy); the weight gradient
+ * dweight[c] += sum_rows dy[r][c] * bf16(x[r][c] * rstd[r]) (fp32 [D], accumulated into) is a
+ * separate call, needed only where decoder layers train (stage "pretrain": the translator layer,
+ * ref:configs/zero/train_llama.py:281-307).
  */
 int zk_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t D,
                    float eps, hipStream_t stream);
 int zk_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd,
                    const void* dres, void* dx, int64_t rows, int64_t D, hipStream_t stream);
+int zk_rmsnorm_dweight(const void* dy, const void* x, const float* rstd, float* dweight,
+                       int64_t rows, int64_t D, hipStream_t stream);
 
 /* ---- RoPE (tf:llama:130-160; cos/sin table tf:llama:113-127) ---------------------------
  * In place on `heads` consecutive heads of width head_dim inside rows of stride ld:

@@ -238,8 +238,22 @@ def make_params(enc: EncoderCfg, dec: DecoderCfg, seed: int, *, surrogate: bool 
     return out
 
 
-def trainable_names(params: Params, encoder_ft_layers_after: int = 16) -> List[str]:
-    """finetune-encoder stage trainable set (configs/zero/train_llama.py:259-323)."""
+def translator_layer_ids(translators_range, num_translators: int) -> List[int]:
+    """Translator indices after the surgery (configs/zero/train_llama.py:290-301)."""
+    ids: List[int] = []
+    for i, r in enumerate(translators_range):
+        o = 0
+        if i > 0:
+            o += sum(len(translators_range[j]) for j in range(i)) - 1
+        ids += [n - o for n in list(r)[:num_translators]]
+    return ids
+
+
+def trainable_names(params: Params, encoder_ft_layers_after: int = 16, stage: str = "finetune-encoder",
+                    translator_ids: Sequence[int] = ()) -> List[str]:
+    """Trainable set by stage (configs/zero/train_llama.py:259-323): the adapter and soi/eoi always;
+    "finetune-encoder": post_layernorm + encoder layers >= encoder_ft_layers_after;
+    "pretrain": post_layernorm + the translator decoder layers."""
     names = []
     for n in params:
         req = False
@@ -247,7 +261,14 @@ def trainable_names(params: Params, encoder_ft_layers_after: int = 16) -> List[s
             req = True
         if "embd_soi" in n or "embd_eoi" in n:
             req = True
-        if "vision_model" in n:
+        if stage == "pretrain":
+            if "vision_model" in n and "post_layernorm" in n:
+                req = True
+            if "decoder" in n and "layers" in n:
+                parts = n.split(".")
+                if int(parts[parts.index("layers") + 1]) in translator_ids:
+                    req = True
+        elif "vision_model" in n:
             if "post_layernorm" in n:
                 req = True
             if "layers" in n:
@@ -497,14 +518,16 @@ class StepOut:
 def train_step(p: Params, enc: EncoderCfg, dec: DecoderCfg, imgs: Sequence[torch.Tensor],
                input_ids, targets, *, img_id: int, pad_id: int, max_seq_len: int = 4096,
                encoder_ft_layers_after: int = 16, want_grads: bool = True,
-               world_tokens: Optional[int] = None, keep_hidden: bool = False) -> StepOut:
+               world_tokens: Optional[int] = None, keep_hidden: bool = False,
+               stage: str = "finetune-encoder") -> StepOut:
     """forward_hf (engine:30-318) from token ids on, plus loss.backward() (train.py:567).
 
     ``world_tokens``: the cross-rank token count after reduce_sum (engine:308-310).
     reduce_sum's backward is the identity (torchshard.py:23-25), so each rank
     back-propagates local_loss_sum / global_tokens; None = 1 rank.
     """
-    names = trainable_names(p, encoder_ft_layers_after) if want_grads else []
+    tids = translator_layer_ids(dec.translators_range, dec.num_translators) if stage == "pretrain" else ()
+    names = trainable_names(p, encoder_ft_layers_after, stage, tids) if want_grads else []
     q: Params = {}
     for k, v in p.items():
         if k in names:

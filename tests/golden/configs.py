@@ -27,6 +27,15 @@ GOLDEN_CONFIGS = {
         seed=2024, ft_after=1, max_seq_len=4096,
         batch=dict(B=2, seed=3, n_pre=21, n_post=40, n_resp=24, ragged=True),
     ),
+    # stage "pretrain" (ref:configs/zero/train_llama.py:281-307): adapter + post_layernorm + the
+    # translator decoder layers train; two translator ranges so the id offset rule is exercised
+    "pretrain": dict(
+        enc=EncoderCfg(hidden=1024, heads=16, intermediate=256, layers=2, image=28, patch=14),
+        dec=DecoderCfg(hidden=256, heads=4, kv_heads=2, head_dim=128, intermediate=384, layers=8,
+                       vocab=512, tie=True, translators_range=((1, 2), (4, 5, 6)), num_translators=1),
+        seed=777, ft_after=0, max_seq_len=4096, stage="pretrain",
+        batch=dict(B=2, seed=9, n_pre=5, n_post=28, n_resp=14, ragged=True),
+    ),
 }
 
 

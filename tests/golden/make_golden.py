@@ -113,7 +113,7 @@ def build_models(enc: zo.EncoderCfg, dec: zo.DecoderCfg, params_full, attn_impl,
     return model
 
 
-def set_trainable(model, ft_after):
+def set_trainable(model, ft_after, stage="finetune-encoder", translator_ids=()):
     # configs/zero/train_llama.py:259-323, TRAINING_STAGE == "finetune-encoder"; the 5.15
     # encoder has no "vision_model" in its names, so the encoder test is made on the
     # "encoder." root instead (same set of tensors).
@@ -122,7 +122,15 @@ def set_trainable(model, ft_after):
         p.requires_grad = False
         if "adapter" in n or "embd_soi" in n or "embd_eoi" in n:
             p.requires_grad = True
-        if n.startswith("encoder."):
+        if stage == "pretrain":
+            # configs/zero/train_llama.py:281-307
+            if n.startswith("encoder.") and "post_layernorm" in n:
+                p.requires_grad = True
+            if "decoder" in n and "layers" in n:
+                parts = n.split(".")
+                if int(parts[parts.index("layers") + 1]) in translator_ids:
+                    p.requires_grad = True
+        elif n.startswith("encoder."):
             if "post_layernorm" in n:
                 p.requires_grad = True
             if "layers" in n:
@@ -198,7 +206,16 @@ def run_config(name, spec):
                              ("bf16", "sdpa", torch.bfloat16)):
         torch.manual_seed(0)
         model = build_models(enc, dec, full, impl, dtype)
-        names = set_trainable(model, spec["ft_after"])
+        stage = spec.get("stage", "finetune-encoder")
+        # translator ids by the reference's own formula (configs/zero/train_llama.py:290-301)
+        tids = []
+        for i, r in enumerate(dec.translators_range):
+            o = 0
+            if i > 0:
+                o += sum(len(dec.translators_range[i]) for i in range(i)) - 1
+            tids.append([n - o for n in list(r)[:dec.num_translators]])
+        tids = sum(tids, [])
+        names = set_trainable(model, spec["ft_after"], stage, tids)
         model.train()
         r = forward_hf_tail(model, [i.to(dtype) for i in imgs], ids, tgts, img_id, pad_id, spec["max_seq_len"])
         r["loss"].backward()
@@ -294,7 +311,10 @@ if __name__ == "__main__":
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("gloo", rank=0, world_size=1)   # reduce_sum queries the world size
     torch.set_num_threads(8)
-    unit_vectors()
+    only = sys.argv[1:]                 # e.g. `make_golden.py pretrain` regenerates one fixture
+    if not only:
+        unit_vectors()
     for name, spec in GOLDEN_CONFIGS.items():
-        run_config(name, spec)
+        if not only or name in only:
+            run_config(name, spec)
     dist.destroy_process_group()

@@ -244,6 +244,19 @@ def test_gemm_rejects_bad_shapes():
         ops.gemm(a.cpu(), b.cpu())
 
 
+def test_rmsnorm_dweight():
+    """dW of LlamaRMSNorm (tf:llama:62-67: w * bf16(x * rstd)) against autograd, accumulate semantics."""
+    for rows, D in ((700, 256), (1536, 3072), (37, 4096)):
+        x, dy, w = rnd(rows, D, seed=71), rnd(rows, D, seed=72), rnd(D, seed=73)
+        _, rstd = ops.rmsnorm_fwd(x, w, 1e-5)
+        acc = torch.full((D,), 0.5, dtype=torch.float32, device=DEV)
+        ops.rmsnorm_dweight_(dy, x, rstd, acc)
+        xf = x.float()
+        xh = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).to(torch.bfloat16).float()
+        ref = (dy.float() * xh).sum(0) + 0.5
+        assert relerr(acc, ref) < 2e-3
+
+
 # ------------------------------------------------------------------ attention
 def ref_attention(q, k, v, causal, scale):
     # q [B,Hq,S,hd] fp32 (requires_grad), k/v [B,Hkv,S,hd]

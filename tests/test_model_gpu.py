@@ -47,6 +47,7 @@ def run_hip(spec, params, imgs, ids, tgts, img_id, pad_id):
     from zero_amd.configs.zero.train_llama import func_optim_filter
     from zero_amd.methods.engine_ar_instruction_llama import forward_from_ids
     cfg = make_cfg(spec["enc"], spec["dec"], DEV, spec["ft_after"], spec["max_seq_len"])
+    cfg.training_stage = spec.get("stage", "finetune-encoder")
     model = build_model(cfg, params)
     func_optim_filter(cfg, model)
     model.train()
@@ -58,7 +59,7 @@ def run_hip(spec, params, imgs, ids, tgts, img_id, pad_id):
     return cfg, model, loss, aux, grads
 
 
-@pytest.mark.parametrize("name", ["tiny", "trunc", "mid"])
+@pytest.mark.parametrize("name", ["tiny", "trunc", "mid", "pretrain"])
 def test_train_step_parity(name, golden_dir):
     spec = GOLDEN_CONFIGS[name]
     gold = load_file(os.path.join(golden_dir, f"{name}.safetensors"))
@@ -68,7 +69,8 @@ def test_train_step_parity(name, golden_dir):
     # (b) live fp32 oracle on the same inputs (images rounded to bf16 like the device path)
     imgs_r = [i.to(torch.bfloat16).float() for i in imgs]
     ref = zo.train_step(params, enc, dec, imgs_r, ids, tgts, img_id=img_id, pad_id=pad_id,
-                        max_seq_len=spec["max_seq_len"], encoder_ft_layers_after=spec["ft_after"])
+                        max_seq_len=spec["max_seq_len"], encoder_ft_layers_after=spec["ft_after"],
+                        stage=spec.get("stage", "finetune-encoder"))
     cfg, model, loss, aux, grads = run_hip(spec, params, imgs, ids, tgts, img_id, pad_id)
 
     report = {}
@@ -118,6 +120,53 @@ def _d_inputs(ref, params, enc, dec, spec, imgs, ids, tgts, img_id, pad_id):
     loss_sum, ntok = zo.loss_tail(logits, ref.target, pad_id)
     (loss_sum / ntok).backward()
     return x.grad
+
+
+def test_pretrain_stage_trainer_slots():
+    """Stage "pretrain" through the Trainer: translator-layer weight gradients land in the flat slots
+    (wgrad kernels write them directly), match the oracle, and the step moves exactly that set."""
+    spec = GOLDEN_CONFIGS["pretrain"]
+    enc, dec = spec["enc"], spec["dec"]
+    params = zo.make_params(enc, dec, spec["seed"], surrogate=True)
+    from tests.helpers import build_model, make_cfg
+    from zero_amd.configs.zero.train_llama import func_optim_filter, translator_layer_ids
+    from zero_amd.methods.engine_ar_instruction_llama import forward_from_ids
+    from zero_amd.train import Trainer
+    cfg = make_cfg(enc, dec, DEV, spec["ft_after"], spec["max_seq_len"])
+    cfg.training_stage = "pretrain"
+    assert translator_layer_ids(cfg) == [1, 3] == zo.translator_layer_ids(dec.translators_range, dec.num_translators)
+    model = build_model(cfg, params)
+    groups = func_optim_filter(cfg, model)
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    assert any(n.startswith("decoder.model.layers.1.self_attn.q_proj") for n in trainable)
+    assert any(n.startswith("decoder.model.layers.3.post_attention_layernorm") for n in trainable)
+    assert not any("vision_model.encoder.layers" in n for n in trainable)
+    assert not any(n.startswith("decoder.model.layers.0.") or n.startswith("decoder.model.norm") for n in trainable)
+    tr = Trainer(cfg, model, forward_from_ids, groups, total_steps=10)
+    try:
+        imgs, ids, tgts, img_id, pad_id = zo.synth_batch(enc, dec, **spec["batch"])
+        imgs_r = [i.to(torch.bfloat16).float() for i in imgs]
+        ref = zo.train_step(params, enc, dec, imgs_r, ids, tgts, img_id=img_id, pad_id=pad_id,
+                            max_seq_len=spec["max_seq_len"], stage="pretrain")
+        assert set(ref.grads) == trainable
+        before = {n: p.detach().float().cpu().clone() for n, p in model.named_parameters()}
+        loss = tr.micro_step([i.to(DEV).to(torch.bfloat16) for i in imgs], ids, tgts, img_id, pad_id)
+        assert abs(loss.item() - ref.loss.item()) <= 1e-2
+        scale = max(v.float().norm().item() / v.numel() ** 0.5 for v in ref.grads.values())
+        worst = ("", 0.0)
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                e = grad_err(p._zk_grad.view(p.shape), ref.grads[n], scale * p.numel() ** 0.5)
+                worst = max(worst, (n, e), key=lambda t: t[1])
+        assert worst[1] <= 3e-2, worst
+        moved = 0
+        for n, p in model.named_parameters():
+            changed = (p.detach().float().cpu() - before[n]).abs().max().item() > 0
+            assert not changed or n in trainable, n      # frozen tensors never move
+            moved += changed and n.startswith("decoder.model.layers.")
+        assert moved >= 14                               # (a norm weight of 1.0 can sit below bf16 resolution)
+    finally:
+        tr.reducer.close()
 
 
 def test_drop_in_forward_list_contract():

@@ -31,7 +31,7 @@ def test_oracle_fp32_matches_golden(name, golden_dir):
     imgs, ids, tgts, img_id, pad_id = zo.synth_batch(enc, dec, **spec["batch"])
     out = zo.train_step(p, enc, dec, imgs, ids, tgts, img_id=img_id, pad_id=pad_id,
                         max_seq_len=spec["max_seq_len"], encoder_ft_layers_after=spec["ft_after"],
-                        keep_hidden=True)
+                        keep_hidden=True, stage=spec.get("stage", "finetune-encoder"))
     assert int(out.num_tokens) == int(gold["fp32.num_tokens"])
     assert torch.equal(out.target, gold["fp32.target"])
     _close(out.loss_sum, gold["fp32.loss_sum"][0], 1e-5, 1e-5, "loss_sum")
@@ -51,6 +51,10 @@ def test_oracle_fp32_matches_golden(name, golden_dir):
             _close(out.grads[n].norm(), gold["fp32.gradnorm." + n][0], 2e-4, 1e-8, "norm " + n)
             n_checked += 1
     assert n_checked == len(out.grads) and n_checked > 6
+    if spec.get("stage") == "pretrain":   # translator layers 1 and 3 of the 5-layer surrogate, no encoder layer
+        assert any(k.startswith("decoder.model.layers.1.") for k in out.grads)
+        assert any(k.startswith("decoder.model.layers.3.mlp.down_proj") for k in out.grads)
+        assert not any(".encoder.layers." in k for k in out.grads)
     # the eager attention path of transformers agrees with sdpa, and so with the oracle
     _close(shrink(out.logits), gold["eager.logits"], 1e-4, 1e-5, "eager logits")
     # encoder hidden states (output_hidden_states=True)

@@ -31,6 +31,7 @@ SIGNATURES = {
     "zk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P],
     "zk_rmsnorm_fwd": [_P, _P, _P, _P, _L, _L, _F, _P],
     "zk_rmsnorm_bwd": [_P, _P, _P, _P, _P, _P, _L, _L, _P],
+    "zk_rmsnorm_dweight": [_P, _P, _P, _P, _L, _L, _P],
     "zk_rope": [_P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
     "zk_swiglu_fwd": [_P, _P, _L, _L, _P],
     "zk_swiglu_bwd": [_P, _P, _P, _L, _L, _P],

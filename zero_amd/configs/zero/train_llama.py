@@ -39,9 +39,21 @@ def func_load_forward():
     return method.forward_hf
 
 
+def translator_layer_ids(cfg):
+    """Indices of the translator layers AFTER the surgery (ref:configs/zero/train_llama.py:290-301,
+    restated with its own offset rule: previous ranges shrink to one surviving layer each)."""
+    ids = []
+    for i, r in enumerate(cfg.translators_range):
+        o = 0
+        if i > 0:
+            o += sum(len(cfg.translators_range[j]) for j in range(i)) - 1
+        ids += [n - o for n in list(r)[:cfg.num_translators]]
+    return ids
+
+
 def func_optim_filter(cfg, model, verbose: bool = False):
-    """Trainable set and AdamW groups by parameter-name substring, stage finetune-encoder
-    (ref:configs/zero/train_llama.py:246-380)."""
+    """Trainable set and AdamW groups by parameter-name substring, stages finetune-encoder and
+    pretrain (ref:configs/zero/train_llama.py:246-380)."""
     decay_params, other_params, encoder_params = [], [], []
     for n, p in model.named_parameters():
         p.requires_grad = False
@@ -62,9 +74,21 @@ def func_optim_filter(cfg, model, verbose: bool = False):
                     if layer_id >= cfg.encoder_ft_layers_after:
                         p.requires_grad = True
                         encoder_params.append(p)
-        elif cfg.training_stage in ("pretrain", "finetune-decoder"):
-            raise NotImplementedError(f"stage {cfg.training_stage}: decoder-side training is a 'next' row "
-                                      "(SURVEY.md §8f row 2)")
+        elif cfg.training_stage == "pretrain":
+            # stage 1: adapter (+ soi/eoi, above), post_layernorm and the translator layer(s) of the
+            # surrogate (ref:configs/zero/train_llama.py:281-307)
+            if "vision_model" in n and "post_layernorm" in n:
+                p.requires_grad = True
+                encoder_params.append(p)
+            if "decoder" in n and "layers" in n:
+                parts = n.split(".")
+                layer_id = int(parts[parts.index("layers") + 1])
+                if layer_id in translator_layer_ids(cfg):
+                    p.requires_grad = True
+                    (decay_params if p.ndim >= 2 else other_params).append(p)
+        elif cfg.training_stage == "finetune-decoder":
+            raise NotImplementedError("stage finetune-decoder: training the whole decoder is outside the built "
+                                      "paths (SURVEY.md §8f)")
         if verbose:
             print(f"p.requires_grad: {str(p.requires_grad):<5}, param: {n}, {tuple(p.shape)}")
     groups = [

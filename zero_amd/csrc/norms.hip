@@ -234,6 +234,61 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, cons
   }
 }
 
+// dw[c] += sum_rows dy[r][c] * bf16(x[r][c] * rstd[r])   (the weight multiplies the bf16-rounded
+// normalised value, tf:llama:67).  Only trainable decoder layers need it (stage "pretrain": the
+// translator layer), so it is its own small kernel rather than a branch of rmsnorm_bwd: one block per
+// CU loops over rows with per-lane column sums in registers, block reduction through LDS, then one
+// atomic per column per block at staggered columns (as layernorm_bwd does for dgamma / dbeta).
+template <int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_dweight_kernel(const bf16_t* dy, const bf16_t* x, const float* rstd_i,
+                                                              float* dw, int rows, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = D >> 3;
+  float ag[MAXV][8];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ag[i][j] = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    u32x4 vx[MAXV], vd[MAXV];
+    load_row<MAXV>(vx, x + (size_t)row * D, nv, lane);
+    load_row<MAXV>(vd, dy + (size_t)row * D, nv, lane);
+    const float rstd = rstd_i[row];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      if (lane + 64 * i < nv) {
+        float fx[8], fd[8];
+        unpack8(vx[i], fx); unpack8(vd[i], fd);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ag[i][j] += fd[j] * bf2f(f2bf(fx[j] * rstd));
+      }
+    }
+  }
+  __shared__ float red[MAXV * 512];
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (w == 0) red[idx * 8 + j] = ag[i][j];
+            else red[idx * 8 + j] += ag[i][j];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int rot = (blockIdx.x * 64) % D;
+  for (int c0 = threadIdx.x; c0 < D; c0 += 256) {
+    int c = c0 + rot;
+    if (c >= D) c -= D;
+    atomicAdd(dw + c, red[c]);
+  }
+}
+
 inline bool bad_dim(int64_t rows, int64_t D) { return rows <= 0 || D <= 0 || (D & 7) || D > 8192 || rows > 0x7FFFFFFF; }
 
 }  // namespace
@@ -289,6 +344,20 @@ extern "C" int zk_rmsnorm_bwd(const void* dy, const void* x, const void* w, cons
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
 #define CALL(V) hipLaunchKernelGGL((rmsnorm_bwd_kernel<V>), grid, block, 0, stream, (const bf16_t*)dy, \
     (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, (int)rows, (int)D)
+  DISPATCH_MAXV(D, CALL)
+#undef CALL
+  ZK_CHECK_LAUNCH();
+  return ZK_OK;
+}
+
+extern "C" int zk_rmsnorm_dweight(const void* dy, const void* x, const float* rstd, float* dweight, int64_t rows,
+                                  int64_t D, hipStream_t stream) {
+  if (!dy || !x || !rstd || !dweight || bad_dim(rows, D)) return ZK_EINVAL;
+  int64_t nb = (rows + 3) / 4;
+  if (nb > 256) nb = 256;
+  dim3 grid((unsigned)nb), block(256);
+#define CALL(V) hipLaunchKernelGGL((rmsnorm_dweight_kernel<V>), grid, block, 0, stream, (const bf16_t*)dy, \
+    (const bf16_t*)x, rstd, dweight, (int)rows, (int)D)
   DISPATCH_MAXV(D, CALL)
 #undef CALL
   ZK_CHECK_LAUNCH();

@@ -341,7 +341,11 @@ class EncoderLayerFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------
-# Llama decoder layer (tf:llama:295-324), frozen weights: dgrad only
+# Llama decoder layer (tf:llama:295-324).  Frozen layers (the surrogate on the finetune-encoder
+# path): dgrad only, resident transposed / interleaved weight copies, fused SwiGLU epilogues.
+# Trainable layers (stage "pretrain": the translator, ref:configs/zero/train_llama.py:281-307):
+# the same forward through the copy-free kernels (the weights change every step), h1 / h2 / hm kept
+# for the seven weight gradients, RMSNorm weight gradients by zk_rmsnorm_dweight.
 # ------------------------------------------------------------------------------------------
 class DecoderLayerFn(torch.autograd.Function):
     """inputs: x [B,S,d]; ln1.w; q.w k.w v.w o.w; ln2.w; gate.w up.w down.w; cos, sin; cfg tuple."""
@@ -351,9 +355,8 @@ class DecoderLayerFn(torch.autograd.Function):
         nh, nkv, hd, eps = dims
         B, S, d = x.shape
         M = B * S
-        need = ctx.needs_input_grad[0]
-        if any(ctx.needs_input_grad[1:10]):
-            raise NotImplementedError("decoder weights are frozen on the encoder-training path (SURVEY.md §8f row 2)")
+        trainable = any(ctx.needs_input_grad[1:10])
+        need = ctx.needs_input_grad[0] or trainable
         x2 = x.reshape(M, d)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
@@ -373,8 +376,9 @@ class DecoderLayerFn(torch.autograd.Function):
         xa = ops.gemm(ao, ow, residual=x2)
         h2, rstd2 = ops.rmsnorm_fwd(xa, l2w, eps, save_stats=need)
         F = gw.shape[0]
-        fused = (FUSE_SWIGLU and USE_TRANSPOSED_FROZEN and F % 32 == 0 and GradSink.slot(gw) is None
-                 and GradSink.slot(uw) is None and GradSink.slot(dw) is None)
+        fused = (FUSE_SWIGLU and USE_TRANSPOSED_FROZEN and F % 32 == 0 and not trainable
+                 and not (gw.requires_grad or uw.requires_grad or dw.requires_grad)
+                 and GradSink.slot(gw) is None and GradSink.slot(uw) is None and GradSink.slot(dw) is None)
         wgu = packed_rows(gw, uw)
         if fused:
             # gate|up GEMM with the SwiGLU in its epilogue; gu is kept in the interleaved column order
@@ -389,21 +393,26 @@ class DecoderLayerFn(torch.autograd.Function):
             hm = ops.swiglu_fwd(gu, F)
         y = ops.gemm(hm, dw, residual=xa)
         if need:
+            extra = (h1, h2, hm) if trainable else (None, None, None)
             ctx.save_for_backward(x2, rstd1, qkv, ao, lse, xa, rstd2, gu, l1w, qw, kw, vw, ow, l2w, gw, uw, dw,
-                                  cos_t, sin_t)
+                                  cos_t, sin_t, *extra)
             ctx.dims = (B, S, d, nh, nkv, hd, F)
             ctx.fused_swiglu = fused
         return y.view(B, S, d)
 
     @staticmethod
     def backward(ctx, dy):
-        (x2, rstd1, qkv, ao, lse, xa, rstd2, gu, l1w, qw, kw, vw, ow, l2w, gw, uw, dw, cos_t, sin_t) = ctx.saved_tensors
+        (x2, rstd1, qkv, ao, lse, xa, rstd2, gu, l1w, qw, kw, vw, ow, l2w, gw, uw, dw, cos_t, sin_t,
+         h1, h2, hm) = ctx.saved_tensors
         B, S, d, nh, nkv, hd, F = ctx.dims
         M = B * S
+        nig = ctx.needs_input_grad
         dy2 = dy.reshape(M, d)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
+        f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=dy.device)
         wgu = packed_rows(gw, uw)
+        g_dw = _wgrad(dy2, hm, dw, nig[9])
         if ctx.fused_swiglu:
             # dh = dy W_down with the SwiGLU backward in the epilogue (interleaved d_gate|d_up), then the
             # dgrad through the interleaved gate|up weight (same K order on both operands)
@@ -416,22 +425,36 @@ class DecoderLayerFn(torch.autograd.Function):
             d_gu = ops.swiglu_bwd(dgrad(dy2, dw), gu, F)
             d_h2 = ops.gemm(d_gu[:, :F], gw, trans_b=True)
             ops.gemm(d_gu[:, F:], uw, trans_b=True, out=d_h2, accumulate=True)
+        g_gw = _wgrad(d_gu[:, :F], h2, gw, nig[7])
+        g_uw = _wgrad(d_gu[:, F:], h2, uw, nig[8])
+        g_l2w = None
+        if nig[6]:
+            g_l2w = _vec_grad(ops.rmsnorm_dweight_(d_h2, xa, rstd2, f32(d)), l2w, True)
         dxa = ops.rmsnorm_bwd(d_h2, xa, l2w, rstd2, dres=dy2)
         d_ao = dgrad(dxa, ow)
+        g_ow = _wgrad(dxa, ao, ow, nig[5])
         d_qkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
         ops.attn_bwd(q, k, v, ao, d_ao, lse, d_qkv[:, :nh * hd], d_qkv[:, nh * hd:(nh + nkv) * hd],
                      d_qkv[:, (nh + nkv) * hd:], B, S, nh, nkv, hd, hd ** -0.5, S > 1)
         ops.rope_(d_qkv, cos_t, sin_t, S, nh + nkv, hd, inverse=True)
+        g_qw = _wgrad(d_qkv[:, :nh * hd], h1, qw, nig[2])
+        g_kw = _wgrad(d_qkv[:, nh * hd:(nh + nkv) * hd], h1, kw, nig[3])
+        g_vw = _wgrad(d_qkv[:, (nh + nkv) * hd:], h1, vw, nig[4])
         wqkv = packed_rows(qw, kw, vw)
-        if wqkv is not None:
-            d_h1 = dgrad(d_qkv, wqkv, owner=qw)
-        else:
-            d_h1 = ops.gemm(d_qkv[:, :nh * hd], qw, trans_b=True)
-            ops.gemm(d_qkv[:, nh * hd:(nh + nkv) * hd], kw, trans_b=True, out=d_h1, accumulate=True)
-            ops.gemm(d_qkv[:, (nh + nkv) * hd:], vw, trans_b=True, out=d_h1, accumulate=True)
-        dx = ops.rmsnorm_bwd(d_h1, x2, l1w, rstd1, dres=dxa)
-        return (dx.view(B, S, d),) + (None,) * 12
+        dx = g_l1w = None
+        if nig[0] or nig[1]:
+            if wqkv is not None:
+                d_h1 = dgrad(d_qkv, wqkv, owner=qw)
+            else:
+                d_h1 = ops.gemm(d_qkv[:, :nh * hd], qw, trans_b=True)
+                ops.gemm(d_qkv[:, nh * hd:(nh + nkv) * hd], kw, trans_b=True, out=d_h1, accumulate=True)
+                ops.gemm(d_qkv[:, (nh + nkv) * hd:], vw, trans_b=True, out=d_h1, accumulate=True)
+            if nig[1]:
+                g_l1w = _vec_grad(ops.rmsnorm_dweight_(d_h1, x2, rstd1, f32(d)), l1w, True)
+            if nig[0]:
+                dx = ops.rmsnorm_bwd(d_h1, x2, l1w, rstd1, dres=dxa).view(B, S, d)
+        return (dx, g_l1w, g_qw, g_kw, g_vw, g_ow, g_l2w, g_gw, g_uw, g_dw, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------

@@ -220,6 +220,16 @@ def rmsnorm_bwd(dy, x, w, rstd, dres=None):
     return dx
 
 
+def rmsnorm_dweight_(dy, x, rstd, dw_f32):
+    """dw_f32 (fp32 [D]) += sum_rows dy * bf16(x * rstd)."""
+    _chk2d(dy, "dy"); _chk2d(x, "x"); _chk_flat(dw_f32, "dw", torch.float32); _chk_flat(rstd, "rstd", torch.float32)
+    if not (dy.is_contiguous() and x.is_contiguous()) or dy.shape != x.shape or dw_f32.numel() != x.shape[1]:
+        raise ValueError("rmsnorm_dweight: contiguous [rows, D] inputs and an fp32 [D] accumulator required")
+    check(lib.zk_rmsnorm_dweight(_p(dy), _p(x), _p(rstd), _p(dw_f32), x.shape[0], x.shape[1], _stream()),
+          "zk_rmsnorm_dweight")
+    return dw_f32
+
+
 def rope_(x2d, cos_t, sin_t, S: int, heads: int, hd: int, inverse: bool = False):
     """In place on the first `heads*hd` columns of the row-strided view x2d."""
     _chk2d(x2d, "x")
