@@ -169,6 +169,62 @@ def test_pretrain_stage_trainer_slots():
         tr.reducer.close()
 
 
+def test_checkpoint_resume_through_trainer(tmp_path):
+    """save_checkpoint / load_checkpoint (reference format) + Trainer.state_dict: one step, save, load
+    into a fresh model + trainer, second step == two steps in one go (up to fp32-atomic ordering)."""
+    import types
+    from tests.helpers import build_model, make_cfg
+    from zero_amd.configs.zero.train_llama import func_optim_filter
+    from zero_amd.methods.engine_ar_instruction_llama import forward_from_ids
+    from zero_amd.train import Trainer
+    from zero_amd.utils import load_checkpoint, save_checkpoint
+    spec = GOLDEN_CONFIGS["tiny"]
+    enc, dec = spec["enc"], spec["dec"]
+    params = zo.make_params(enc, dec, spec["seed"], surrogate=True)
+    batches = [zo.synth_batch(enc, dec, **{**spec["batch"], "seed": s}) for s in (21, 22)]
+
+    def fresh():
+        cfg = make_cfg(enc, dec, DEV, spec["ft_after"], spec["max_seq_len"])
+        cfg.lr = 1e-3
+        model = build_model(cfg, params)
+        tr = Trainer(cfg, model, forward_from_ids, func_optim_filter(cfg, model), total_steps=50)
+        return cfg, model, tr
+
+    def run(tr, b):
+        imgs, ids, tgts, img_id, pad_id = b
+        return tr.micro_step([i.to(DEV).to(torch.bfloat16) for i in imgs], ids, tgts, img_id, pad_id)
+
+    _, model_a, tr_a = fresh()
+    try:
+        run(tr_a, batches[0]); run(tr_a, batches[1])
+    finally:
+        tr_a.reducer.close()
+    _, model_b, tr_b = fresh()
+    args = types.SimpleNamespace(ckpt_dir=str(tmp_path), exp_code="resume")
+    try:
+        run(tr_b, batches[0])
+        path = save_checkpoint(args, model_b, tr_b, None, epoch=0, global_step=tr_b.global_step)
+    finally:
+        tr_b.reducer.close()
+    _, model_c, tr_c = fresh()
+    try:
+        assert load_checkpoint(path, model_c, optimizer=tr_c, strict=False) == (0, 1)
+        assert tr_c.global_step == 1
+        run(tr_c, batches[1])
+    finally:
+        tr_c.reducer.close()
+    pa = dict(model_a.named_parameters())
+    for n, p in model_c.named_parameters():
+        if p.requires_grad:
+            # Adam's step is ~lr * sign-like: an element whose tiny gradient rounds differently (fp32
+            # atomics order in the norm backward) may move by up to ~2 lr; a lost optimizer state would
+            # move EVERY element by ~lr, which the mean bound catches
+            d = (pa[n].detach().float() - p.detach().float()).abs()
+            # (k_proj.bias has an analytically zero gradient: Adam amplifies its rounding noise, grad_err above)
+            mean_ok = d.mean().item() <= 5e-5 or "k_proj.bias" in n
+            assert d.max().item() <= 2.5e-3 and mean_ok, (n, d.max().item(), d.mean().item())
+
+
 def test_drop_in_forward_list_contract():
     """Zero._forward returns bs * [1 + P*T + 1, d] (adapter.py:116) and matches the oracle."""
     spec = GOLDEN_CONFIGS["tiny"]

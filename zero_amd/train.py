@@ -93,3 +93,24 @@ class Trainer:
 
     def grad_norm(self) -> torch.Tensor:
         return self.sumsq.sqrt()
+
+    # ---- optimizer state for utils.save_checkpoint / load_checkpoint (ref:utils.py:357-360,504-508)
+    def state_dict(self) -> dict:
+        """Adam moments per parameter NAME (layout independent), fp32, plus the step counters."""
+        r = self.reducer
+        m, v = {}, {}
+        for p in r.params:
+            o, n = r.offset[id(p)], p.numel()
+            m[r.names[id(p)]] = self.m[o:o + n].detach().to("cpu", copy=True).view(p.shape)
+            v[r.names[id(p)]] = self.v[o:o + n].detach().to("cpu", copy=True).view(p.shape)
+        return {"exp_avg": m, "exp_avg_sq": v, "global_step": self.global_step, "micro": self._micro}
+
+    def load_state_dict(self, sd: dict):
+        r = self.reducer
+        for p in r.params:
+            o, n, name = r.offset[id(p)], p.numel(), r.names[id(p)]
+            if name in sd["exp_avg"]:
+                self.m[o:o + n].copy_(sd["exp_avg"][name].reshape(-1))
+                self.v[o:o + n].copy_(sd["exp_avg_sq"][name].reshape(-1))
+        self.global_step = int(sd.get("global_step", 0))
+        self._micro = int(sd.get("micro", 0))
