@@ -203,6 +203,11 @@ int zk_adamw_step(void* p, const void* g, float* m, float* v, int64_t n, float l
  */
 int zk_f32_to_bf16(const float* src, void* dst, int64_t n, float scale, int accumulate,
                    hipStream_t stream);
+/* The same for up to 16 independent segments in one launch (host arrays of `count` entries): the
+ * bias / norm-affine gradients of one layer, each converted from its fp32 accumulator into its own
+ * slot of the flat gradient buffer. */
+int zk_f32_to_bf16_multi(const float* const* src, void* const* dst, const int64_t* n,
+                         const int* accumulate, int count, float scale, hipStream_t stream);
 
 #ifdef __cplusplus
 }

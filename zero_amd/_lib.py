@@ -44,6 +44,7 @@ SIGNATURES = {
     "zk_sumsq": [_P, _P, _L, _F, _P],
     "zk_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P, _F, _P],
     "zk_f32_to_bf16": [_P, _P, _L, _F, _I, _P],
+    "zk_f32_to_bf16_multi": [_P, _P, _P, _P, _I, _F, _P],
 }
 
 for _name, _args in SIGNATURES.items():

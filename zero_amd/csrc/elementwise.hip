@@ -325,6 +325,27 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* src, bf16
   }
 }
 
+// Up to 16 independent (fp32 source, bf16 destination, length, accumulate) segments in ONE launch: the
+// vector gradients of a layer (biases, norm affines) each live in their own slot of the flat gradient
+// buffer; blockIdx.y picks the segment, the table travels in the kernel arguments.
+struct CvtSegs {
+  const float* src[16];
+  bf16_t* dst[16];
+  int n[16];
+  int accumulate[16];
+};
+__global__ __launch_bounds__(256) void f32_to_bf16_multi_kernel(CvtSegs t, float scale) {
+  const int s = blockIdx.y;
+  const float* src = t.src[s];
+  bf16_t* dst = t.dst[s];
+  const int n = t.n[s], acc = t.accumulate[s];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    float v = src[i] * scale;
+    if (acc) v += bf2f(dst[i]);
+    dst[i] = f2bf(v);
+  }
+}
+
 inline unsigned grid_for(int64_t work_items, int64_t cap = 256 * 16) {
   int64_t b = (work_items + 255) / 256;
   if (b < 1) b = 1;
@@ -444,6 +465,22 @@ extern "C" int zk_f32_to_bf16(const float* src, void* dst, int64_t n, float scal
   if (!src || !dst || n <= 0) return ZK_EINVAL;
   hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, stream, src, (bf16_t*)dst, n, scale,
                      accumulate);
+  ZK_CHECK_LAUNCH();
+  return ZK_OK;
+}
+
+extern "C" int zk_f32_to_bf16_multi(const float* const* src, void* const* dst, const int64_t* n, const int* accumulate,
+                                    int count, float scale, hipStream_t stream) {
+  if (!src || !dst || !n || !accumulate || count <= 0 || count > 16) return ZK_EINVAL;
+  CvtSegs t;
+  int64_t longest = 0;
+  for (int i = 0; i < 16; ++i) {
+    const int j = i < count ? i : 0;
+    if (!src[j] || !dst[j] || n[j] <= 0 || n[j] > 0x7FFFFFFF) return ZK_EINVAL;
+    t.src[i] = src[j]; t.dst[i] = (bf16_t*)dst[j]; t.n[i] = (int)n[j]; t.accumulate[i] = accumulate[j];
+    if (n[j] > longest) longest = n[j];
+  }
+  hipLaunchKernelGGL(f32_to_bf16_multi_kernel, dim3(grid_for(longest, 64), (unsigned)count), dim3(256), 0, stream, t, scale);
   ZK_CHECK_LAUNCH();
   return ZK_OK;
 }

@@ -23,10 +23,34 @@ BF16 = torch.bfloat16
 # ------------------------------------------------------------------------------------------
 # gradient sinks
 # ------------------------------------------------------------------------------------------
+class ZeroArena:
+    """fp32 scratch for the per-backward vector-gradient accumulators (bias / norm-affine sums): one
+    buffer, zeroed by ONE fill per backward, handed out in 64-element-aligned slices — instead of a
+    torch.zeros launch per accumulator (8 per encoder layer)."""
+
+    def __init__(self, device, numel: int = 1 << 20):
+        self.buf = torch.zeros(numel, dtype=torch.float32, device=device)
+        self.ptr = 0
+
+    def reset(self):
+        self.buf.zero_()
+        self.ptr = 0
+
+    def take(self, n: int) -> Optional[torch.Tensor]:
+        start = self.ptr
+        end = start + (n + 63) // 64 * 64
+        if end > self.buf.numel():
+            return None
+        self.ptr = end
+        return self.buf[start:start + n]
+
+
 class GradSink:
     """Routes a parameter gradient either into its flat-buffer slot or back to autograd."""
 
     listeners = []          # callables(param) fired when a slot has received its gradient
+    arena: Optional[ZeroArena] = None   # set by the Trainer for the duration of its life
+    pending = []            # (fp32 accumulator, bf16 slot, accumulate, param): converted by flush()
 
     @staticmethod
     def slot(p: torch.Tensor) -> Optional[torch.Tensor]:
@@ -41,6 +65,26 @@ class GradSink:
         p._zk_dirty = True
         for fn in GradSink.listeners:
             fn(p)
+
+    @staticmethod
+    def zeros(n: int, device) -> torch.Tensor:
+        a = GradSink.arena
+        if a is not None and a.buf.device == torch.device(device):
+            t = a.take(n)
+            if t is not None:
+                return t
+        return torch.zeros(n, dtype=torch.float32, device=device)
+
+    @staticmethod
+    def flush():
+        """One conversion launch for every vector gradient queued since the last flush (called at the
+        end of each layer node's backward), then the slot notifications."""
+        if not GradSink.pending:
+            return
+        batch, GradSink.pending = GradSink.pending, []
+        ops.f32_to_bf16_multi_([(a, s_, acc) for a, s_, acc, _ in batch])
+        for _, _, _, p in batch:
+            GradSink.done(p)
 
 
 # ------------------------------------------------------------------------------------------
@@ -108,8 +152,7 @@ def _vec_grad(acc_f32: torch.Tensor, p: torch.Tensor, need: bool):
         return None
     slot = GradSink.slot(p)
     if slot is not None:
-        ops.f32_to_bf16_(acc_f32, slot, accumulate=GradSink.is_dirty(p))
-        GradSink.done(p)
+        GradSink.pending.append((acc_f32, slot, GradSink.is_dirty(p), p))   # converted by GradSink.flush()
         return None
     out = torch.empty(p.shape, dtype=BF16, device=p.device)
     ops.f32_to_bf16_(acc_f32, out)
@@ -119,7 +162,7 @@ def _vec_grad(acc_f32: torch.Tensor, p: torch.Tensor, need: bool):
 def _bias_grad(dy2d, b: torch.Tensor, need: bool):
     if not need:
         return None
-    acc = torch.zeros(b.numel(), dtype=torch.float32, device=dy2d.device)
+    acc = GradSink.zeros(b.numel(), dy2d.device)
     ops.colsum_(dy2d, acc)
     return _vec_grad(acc, b, True)
 
@@ -181,6 +224,7 @@ class LinearFn(torch.autograd.Function):
             dx = dgrad(dy2, w).view(*dy.shape[:-1], w.shape[1])
         dw = _wgrad(dy2, x2, w, ctx.needs_input_grad[1])
         db = _bias_grad(dy2, b, b is not None and ctx.needs_input_grad[2])
+        GradSink.flush()
         return dx, dw, db, None
 
 
@@ -203,11 +247,13 @@ class LayerNormFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         D = x2.shape[1]
-        dg = torch.zeros(D, dtype=torch.float32, device=x2.device) if need_p else None
-        db = torch.zeros(D, dtype=torch.float32, device=x2.device) if need_p else None
+        dg = GradSink.zeros(D, x2.device) if need_p else None
+        db = GradSink.zeros(D, x2.device) if need_p else None
         dx = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dgamma=dg, dbeta=db, need_dx=ctx.needs_input_grad[0])
-        return (dx.view(dy.shape) if dx is not None else None, _vec_grad(dg, gamma, ctx.needs_input_grad[1]),
-                _vec_grad(db, beta, ctx.needs_input_grad[2]), None)
+        out = (dx.view(dy.shape) if dx is not None else None, _vec_grad(dg, gamma, ctx.needs_input_grad[1]),
+               _vec_grad(db, beta, ctx.needs_input_grad[2]), None)
+        GradSink.flush()
+        return out
 
 
 class RMSNormFn(torch.autograd.Function):
@@ -281,7 +327,7 @@ class EncoderLayerFn(torch.autograd.Function):
         dy2 = dy.reshape(M, D)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+        f32 = lambda n: GradSink.zeros(n, dev)
         # ---- MLP block:  y = xa + fc2(quick_gelu(fc1(LN2(xa))))
         d_pre = ops.gemm(dy2, f2w, trans_b=True, epilogue=ops.EPI_MUL_DQUICK_GELU, aux_in=pre)
         g_f2w = _wgrad(dy2, act, f2w, nig[15])
@@ -318,9 +364,9 @@ class EncoderLayerFn(torch.autograd.Function):
         if nig[4] or nig[6] or nig[8]:
             acc = f32(3 * D)
             ops.colsum_(d_qkv, acc)
-            g_qb = _vec_grad(acc[:D].contiguous(), qb, nig[4])
-            g_kb = _vec_grad(acc[D:2 * D].contiguous(), kb, nig[6])
-            g_vb = _vec_grad(acc[2 * D:].contiguous(), vb, nig[8])
+            g_qb = _vec_grad(acc[:D], qb, nig[4])
+            g_kb = _vec_grad(acc[D:2 * D], kb, nig[6])
+            g_vb = _vec_grad(acc[2 * D:], vb, nig[8])
         need_dx = nig[0]
         dx = None
         g_l1w = g_l1b = None
@@ -336,6 +382,7 @@ class EncoderLayerFn(torch.autograd.Function):
             g_l1w, g_l1b = _vec_grad(dg1, l1w, nig[1]), _vec_grad(db1, l1b, nig[2])
             if dx is not None:
                 dx = dx.view(B, T, D)
+        GradSink.flush()
         return (dx, g_l1w, g_l1b, g_qw, g_qb, g_kw, g_kb, g_vw, g_vb, g_ow, g_ob, g_l2w, g_l2b,
                 g_f1w, g_f1b, g_f2w, g_f2b, None, None)
 
@@ -410,7 +457,7 @@ class DecoderLayerFn(torch.autograd.Function):
         dy2 = dy.reshape(M, d)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=dy.device)
+        f32 = lambda n: GradSink.zeros(n, dy.device)
         wgu = packed_rows(gw, uw)
         g_dw = _wgrad(dy2, hm, dw, nig[9])
         if ctx.fused_swiglu:
@@ -454,6 +501,7 @@ class DecoderLayerFn(torch.autograd.Function):
                 g_l1w = _vec_grad(ops.rmsnorm_dweight_(d_h1, x2, rstd1, f32(d)), l1w, True)
             if nig[0]:
                 dx = ops.rmsnorm_bwd(d_h1, x2, l1w, rstd1, dres=dxa).view(B, S, d)
+        GradSink.flush()
         return (dx, g_l1w, g_qw, g_kw, g_vw, g_ow, g_l2w, g_gw, g_uw, g_dw, None, None, None)
 
 
@@ -489,6 +537,7 @@ class AdapterFn(torch.autograd.Function):
         dx = ops.gemm(d_pre, w0, trans_b=True) if nig[0] else None
         if dx is not None:
             dx = dx.view(*dy.shape[:-1], w0.shape[1])
+        GradSink.flush()
         return dx, g_w0, g_b0, g_w2, g_b2
 
 
@@ -529,9 +578,10 @@ class SpliceFn(torch.autograd.Function):
                 outs.append(None)
                 continue
             rows = ops.gather_rows(dy2, None, pos, d)
-            acc = torch.zeros(d, dtype=torch.float32, device=dy.device)
+            acc = GradSink.zeros(d, dy.device)
             ops.colsum_(rows, acc)
             outs.append(_vec_grad(acc, p, True))
+        GradSink.flush()
         return (d_img, outs[0], outs[1]) + (None,) * 7
 
 

@@ -327,6 +327,25 @@ def f32_to_bf16_(src, dst, scale: float = 1.0, accumulate: bool = False):
     return dst
 
 
+def f32_to_bf16_multi_(pairs, scale: float = 1.0):
+    """pairs: list of (src fp32 flat, dst bf16 flat, accumulate) — ONE launch per 16 segments."""
+    import ctypes
+    for i in range(0, len(pairs), 16):
+        chunk = pairs[i:i + 16]
+        k = len(chunk)
+        srcs = (ctypes.c_void_p * k)(*[s_.data_ptr() for s_, _, _ in chunk])
+        dsts = (ctypes.c_void_p * k)(*[d_.data_ptr() for _, d_, _ in chunk])
+        ns = (ctypes.c_int64 * k)(*[s_.numel() for s_, _, _ in chunk])
+        accs = (ctypes.c_int * k)(*[int(a_) for _, _, a_ in chunk])
+        for s_, d_, _ in chunk:
+            if s_.dtype != torch.float32 or d_.dtype != BF16 or s_.numel() != d_.numel() or not (
+                    s_.is_contiguous() and d_.is_contiguous()):
+                raise ValueError("f32_to_bf16_multi: (fp32, bf16) contiguous pairs of equal length required")
+        check(lib.zk_f32_to_bf16_multi(ctypes.cast(srcs, ctypes.c_void_p), ctypes.cast(dsts, ctypes.c_void_p),
+                                       ctypes.cast(ns, ctypes.c_void_p), ctypes.cast(accs, ctypes.c_void_p), k,
+                                       float(scale), _stream()), "zk_f32_to_bf16_multi")
+
+
 def set_gemm_tile(cfg: int = -1):
     """Tuning hook: force the GEMM block tile (-1 cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256)."""
     check(lib.zk_gemm_set_tile(int(cfg)), "zk_gemm_set_tile")

@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from . import ops
 from .distributed.ddp import FlatGradReducer
+from .functional import GradSink, ZeroArena
 
 
 class Trainer:
@@ -30,6 +31,7 @@ class Trainer:
         self.m = torch.zeros(r.numel, dtype=torch.float32, device=dev)
         self.v = torch.zeros(r.numel, dtype=torch.float32, device=dev)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.arena = ZeroArena(dev)             # per-backward fp32 accumulators of the vector gradients
         # (lr, wd) per parameter from the reference-style groups, merged into contiguous segments
         hp = {}
         for g in optim_groups:
@@ -65,6 +67,8 @@ class Trainer:
             r.begin_step()
         loss = self.forward(self.cfg, *fwd_args, **fwd_kwargs)             # train.py:524
         scaled = loss / self.accum                                          # train.py:527
+        GradSink.arena = self.arena
+        self.arena.reset()
         if last:
             scaled.backward()                                               # train.py:567
             r.finish_backward()
@@ -73,6 +77,7 @@ class Trainer:
             with r.no_sync():                                               # train.py:562-564
                 scaled.backward()
                 r.finish_backward()
+        GradSink.arena = None
         self._micro += 1
         return loss.detach()
 
