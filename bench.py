@@ -10,6 +10,8 @@ Workloads (--workload):
     c3 (default)  Llama-3.2-3B surrogate (18 layers) step, B = 8 per GPU, S = 768   [configs[2]]
     c4            Llama-3.1-8B surrogate (19 layers) step, B = 8 per GPU, S = 768   [configs[3]]
     c2            ViT encoder + adapter forward/backward only, B = 64               [configs[1]]
+    c5            zero-shot graft inference on Llama-3.1-70B, tensor parallel over --gpus ranks (RCCL);
+                  on ONE GPU: rank 0's shard of a --tp-way split, collectives skipped     [configs[4]]
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -33,7 +35,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--new-tokens", type=int, default=32, help="c5: greedy decode steps that are timed")
+    ap.add_argument("--tp", type=int, default=8, help="c5 on one GPU: the tensor-parallel degree whose rank-0 shard is timed")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 8; 64 for c2)")
     ap.add_argument("--stage", default="finetune-encoder", choices=["finetune-encoder", "pretrain"],
                     help="training stage of ref:configs/zero/train_llama.py (pretrain = adapter + translator layer)")
@@ -115,6 +119,9 @@ def main():
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
             os.environ["ZERO_AMD_FORCE_ALLREDUCE"] = "1"
         dist.init_process_group("nccl", device_id=device)
+
+    if args.workload == "c5":
+        return bench_c5(args, world, rank, device)
 
     from oracle import zero_oracle as zo   # cpu_baseline leg + synthetic batch generator only
     from zero_amd import ops
@@ -339,6 +346,99 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_dist:
+        dist.destroy_process_group()
+
+
+def bench_c5(args, world, rank, device):
+    """Graft inference (ref:inference/vlm_infer.py:191-270) on the FULL Llama-3.1-70B: encoder + adapter
+    prefix, prefill of the 768-token prompt, then greedy decoding with a KV cache.  Each rank holds 1/W
+    of every layer (distributed/tensor_parallel.py); with one GPU the rank-0 shard of a --tp split is
+    built directly (same shapes, random init) and the all-reduces are skipped (compute-only number)."""
+    from oracle import zero_oracle as zo
+    from zero_amd.build_encoder import load_clip
+    from zero_amd.configs.config_base import LLAMA_SHAPES
+    from zero_amd.configs.zero import train_llama as run_cfg
+    from zero_amd.distributed.tensor_parallel import TPContext
+    from zero_amd.inference.decode import KVCache, forward_cached
+    from zero_amd.inference.vlm_infer import graft_inputs
+    from zero_amd.models.adapter import Zero
+    from zero_amd.models.llama import LlamaConfig, LlamaForCausalLM
+    import copy
+    W = world if world > 1 else args.tp
+    sh = dict(LLAMA_SHAPES[("3.1", "70")])
+    sh.pop("translators_range")
+    factor = sh.pop("rope_factor")
+    full = LlamaConfig(**sh)
+    lcfg = LlamaConfig(**{**sh, "num_attention_heads": full.num_attention_heads // W,
+                          "num_key_value_heads": full.num_key_value_heads // W,
+                          "intermediate_size": full.intermediate_size // W})
+    lcfg.rope_scaling = dict(rope_type="llama3", factor=factor, low_freq_factor=1.0, high_freq_factor=4.0,
+                             original_max_position_embeddings=8192)
+    cfg = copy.deepcopy(run_cfg.config)
+    cfg.device, cfg.enable_translator, cfg.num_embd = device, False, lcfg.hidden_size
+    torch.manual_seed(1337 + rank)                 # each rank draws its own shard
+    quiet = open(os.devnull, "w")
+    stdout, sys.stdout = sys.stdout, quiet
+    try:
+        encoder, _, img_size = load_clip(cfg)
+        decoder = LlamaForCausalLM(lcfg, device=device)          # shard-shaped layers, replicated embed / lm_head
+    finally:
+        sys.stdout = stdout
+    torch.manual_seed(1337)                        # replicated tensors must agree across ranks
+    with torch.no_grad():
+        decoder.model.embed_tokens.weight.normal_(0.0, 0.02)
+        decoder.lm_head.weight.normal_(0.0, 0.02)
+    model = Zero(cfg, encoder, decoder)
+    model.eval()
+    tp = TPContext(rank, world, None) if world > 1 else TPContext()
+    imgs_cpu, ids, _, img_id, _ = zo.synth_batch(zo.EncoderCfg(), zo.DecoderCfg(vocab=128256), 1, 1337, n_pre=21,
+                                                 n_post=168, n_resp=1)
+    imgs = [i.to(device).to(torch.bfloat16) for i in imgs_cpu]
+    nl, kvw = len(decoder.model.layers), lcfg.num_key_value_heads * lcfg.head_dim
+    wte = decoder.model.get_input_embeddings()
+
+    def one_pass(n_new):
+        x = graft_inputs(model, imgs, ids, img_id)
+        cache = KVCache(nl, 1, x.shape[1] + n_new, kvw, device)
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True); t2 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        logits = forward_cached(decoder, x, cache, tp)
+        t1.record()
+        for _ in range(n_new):
+            nxt = logits[:, 0].float().argmax(-1)
+            logits = forward_cached(decoder, wte(nxt.view(1, 1)), cache, tp)
+        t2.record()
+        torch.cuda.synchronize()
+        return x.shape[1], t0.elapsed_time(t1), t1.elapsed_time(t2)
+
+    for _ in range(max(1, args.warmup // 2)):
+        one_pass(4)
+    if world > 1:
+        dist.barrier()
+    pre, decs = [], []
+    for _ in range(max(1, args.steps // 3)):
+        S, a, b = one_pass(args.new_tokens)
+        pre.append(a); decs.append(b)
+    pre_ms, dec_ms = sorted(pre)[len(pre) // 2], sorted(decs)[len(decs) // 2]
+    if world > 1:
+        t = torch.tensor([pre_ms, dec_ms], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        pre_ms, dec_ms = t.tolist()
+    if rank == 0:
+        per_tok = 2.0 * sum(p.numel() for n, p in decoder.named_parameters() if "embed_tokens" not in n)
+        print(json.dumps({
+            "metric": "zero-shot graft inference on Llama-3.1-70B: decode tokens/sec (one sequence)",
+            "value": round(args.new_tokens / (dec_ms * 1e-3), 2), "unit": "tokens/sec", "n_gpus": world,
+            "higher_is_better": True, "dtype": "bf16", "data": "synthetic",
+            "prefill_ms": round(pre_ms, 2), "prefill_tokens": S, "decode_ms_per_token": round(dec_ms / args.new_tokens, 3),
+            "config": {"workload": "encoder + adapter prefix, 768-token prompt prefill, greedy KV-cache decoding on "
+                                   "Llama-3.1-70B (80 layers), tensor parallel", "tp_degree": W,
+                       "collectives": "RCCL all-reduce, 2 per layer" if world > 1 else
+                                      "skipped: ONE rank's shard timed on one GPU (compute only)",
+                       "weights": "seeded random init", "new_tokens": args.new_tokens},
+            "decode_weight_gb_per_token_per_gpu": round(per_tok / 1e9, 2),
+            "decode_weight_stream_gbs": round(per_tok / 1e9 / (dec_ms * 1e-3 / args.new_tokens), 1)}), flush=True)
+    if world > 1:
         dist.destroy_process_group()
 
 

@@ -107,6 +107,17 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
                 int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale,
                 int causal, hipStream_t stream);
 
+/* Single-query attention over a KV cache: one new token per sequence against `lens[b]` cached keys
+ * (the current token's k/v already appended), as tf generate(use_cache=True) does for the reference's
+ * greedy decoding (ref:inference/vlm_infer.py:259-270; tf:llama:264-277 with a DynamicCache).
+ * q [B][Hq*hd] (row stride ldq); caches [B][max rows][Hkv*hd] with row strides ldk / ldv and batch
+ * strides in elements; lens int32 [B] on the device; out [B][Hq*hd].  head_dim 64 or 128,
+ * max_len (the largest lens[b]) <= 15000. */
+int zk_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out,
+                   const int* lens, int64_t B, int64_t Hq, int64_t Hkv, int64_t head_dim,
+                   int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t batch_stride_k,
+                   int64_t batch_stride_v, int64_t max_len, float scale, hipStream_t stream);
+
 /* ---- LayerNorm (tf:clip:358-360,370,379,605,642; ref:adapter.py:94) ------------------
  * y = (x - mean) * rstd * gamma + beta over the last dim D (<= 8192, multiple of 8),
  * fp32 statistics.  mean/rstd [rows] fp32 are optional outputs of fwd (needed by bwd).

@@ -552,6 +552,38 @@ def train_step(p: Params, enc: EncoderCfg, dec: DecoderCfg, imgs: Sequence[torch
 
 
 # --------------------------------------------------------------------------
+# zero-shot graft inference (inference/vlm_infer.py:201-270): greedy decoding
+# --------------------------------------------------------------------------
+def greedy_generate(p: Params, inputs_embeds: torch.Tensor, dec: DecoderCfg, max_new_tokens: int,
+                    eos_ids: Sequence[int] = (), pad_id: Optional[int] = None, return_logits: bool = False):
+    """What tf generate(inputs_embeds=…, do_sample=False, use_cache=True) computes, restated without a
+    cache: every step re-runs the full causal forward on the grown sequence (small cases only) and
+    takes the argmax of the last position; finished sequences emit ``pad_id``; stops when all are
+    finished.  Returns new ids [B, n] (and the per-step last-position logits)."""
+    wte = p["decoder.model.embed_tokens.weight"]
+    x = inputs_embeds
+    B = x.shape[0]
+    done = torch.zeros(B, dtype=torch.bool)
+    out, step_logits = [], []
+    with torch.no_grad():
+        for _ in range(max_new_tokens):
+            logits = llama_forward(p, x, dec)[:, -1].float()
+            step_logits.append(logits)
+            nxt = logits.argmax(-1)
+            if eos_ids:
+                nxt = torch.where(done, torch.full_like(nxt, pad_id if pad_id is not None else eos_ids[0]), nxt)
+            out.append(nxt)
+            if eos_ids:
+                for e in eos_ids:
+                    done |= nxt == e
+                if bool(done.all()):
+                    break
+            x = torch.cat([x, F.embedding(nxt, wte)[:, None].to(x.dtype)], dim=1)
+    toks = torch.stack(out, dim=1)
+    return (toks, step_logits) if return_logits else toks
+
+
+# --------------------------------------------------------------------------
 # step tail: clip + AdamW  (train.py:382-387, 570-580)
 # --------------------------------------------------------------------------
 def clip_and_adamw(params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor],

@@ -36,6 +36,14 @@ GOLDEN_CONFIGS = {
         seed=777, ft_after=0, max_seq_len=4096, stage="pretrain",
         batch=dict(B=2, seed=9, n_pre=5, n_post=28, n_resp=14, ragged=True),
     ),
+    # zero-shot graft inference (ref:inference/vlm_infer.py): FULL decoder (no surgery), greedy decoding
+    "graft": dict(
+        enc=EncoderCfg(hidden=1024, heads=16, intermediate=256, layers=2, image=28, patch=14),
+        dec=DecoderCfg(hidden=256, heads=4, kv_heads=2, head_dim=128, intermediate=512, layers=4,
+                       vocab=512, tie=False, translators_range=(), num_translators=1),
+        seed=31337, ft_after=0, max_seq_len=4096, graft=True, max_new_tokens=12,
+        batch=dict(B=2, seed=17, n_pre=6, n_post=9, n_resp=1, ragged=False),
+    ),
 }
 
 

@@ -255,6 +255,42 @@ def run_config(name, spec):
           "bf16 loss", float(out["bf16.loss"]))
 
 
+def run_graft(name, spec):
+    """ref:inference/vlm_infer.py:201-270 on the real modules: Zero._forward, splice at the image token,
+    pad_sequence, then transformers' own generate (greedy, KV cache)."""
+    enc, dec = spec["enc"], spec["dec"]
+    full = zo.make_params(enc, dec, spec["seed"], surrogate=False)
+    imgs, ids, _, img_id, _ = zo.synth_batch(enc, dec, **spec["batch"])
+    out = {}
+    torch.manual_seed(0)
+    model = build_models(enc, dec, full, "sdpa", torch.float32)
+    model.eval()
+    model.requires_grad_(False)
+    with torch.inference_mode():
+        embds_imgs = model._forward(imgs)                                  # vlm_infer.py:201
+        wte = model.decoder.model.get_input_embeddings()
+        input_embds = []
+        for i, input_id in enumerate(ids):
+            at = input_id.index(img_id)
+            e1 = wte(torch.tensor(input_id[:at], dtype=torch.long))
+            e2 = wte(torch.tensor(input_id[at + 1:], dtype=torch.long))
+            input_embds.append(torch.cat([e1, embds_imgs[i], e2], dim=0))
+        input_embds = pad_sequence(input_embds, batch_first=True, padding_value=0.0)
+        mask = torch.ones(input_embds.shape[0], input_embds.shape[1])
+        gc = model.decoder.generation_config
+        gc.eos_token_id = None
+        gc.pad_token_id = None
+        toks = model.decoder.generate(inputs_embeds=input_embds, attention_mask=mask, do_sample=False,
+                                      max_new_tokens=spec["max_new_tokens"], use_cache=True)
+        logits = model.decoder(inputs_embeds=input_embds, use_cache=False)["logits"]
+    out["fp32.gen_tokens"] = toks.clone()
+    out["fp32.inputs_embeds"] = shrink(input_embds.float().clone())
+    out["fp32.prompt_last_logits"] = logits[:, -1].float().clone()
+    path = os.path.join(HERE, f"{name}.safetensors")
+    save_file({k: v.contiguous() for k, v in out.items()}, path)
+    print(name, "->", path, "tokens", toks.tolist())
+
+
 def unit_vectors():
     """Small known-answer vectors straight from the transformers modules."""
     from transformers.models.llama.modeling_llama import LlamaRMSNorm, LlamaRotaryEmbedding, apply_rotary_pos_emb
@@ -316,5 +352,5 @@ if __name__ == "__main__":
         unit_vectors()
     for name, spec in GOLDEN_CONFIGS.items():
         if not only or name in only:
-            run_config(name, spec)
+            (run_graft if spec.get("graft") else run_config)(name, spec)
     dist.destroy_process_group()

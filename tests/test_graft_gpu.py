@@ -1,0 +1,147 @@
+"""Zero-shot graft inference on the GPU: single-query attention kernel, KV-cache decoding against a
+full recompute (HIP training-path forward and the fp32 oracle), greedy generation against the golden
+transformers run, and the tensor-parallel path (W = 2 rank threads on one device)."""
+import os
+import threading
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from oracle import zero_oracle as zo
+from tests.golden.configs import GOLDEN_CONFIGS
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def maxrel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+def _model(spec):
+    from tests.helpers import build_model, make_cfg
+    enc, dec = spec["enc"], spec["dec"]
+    params = zo.make_params(enc, dec, spec["seed"], surrogate=False)
+    cfg = make_cfg(enc, dec, DEV, spec["ft_after"], spec["max_seq_len"])
+    cfg.enable_translator = False                                     # ref:vlm_infer.py:57
+    model = build_model(cfg, params)
+    model.eval()
+    return params, cfg, model
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,hd,rows,lens", [(2, 4, 2, 128, 300, (300, 123)), (1, 8, 1, 128, 1030, (1027,)),
+                                                   (3, 6, 6, 64, 70, (1, 64, 70))])
+def test_attn_decode_kernel(B, Hq, Hkv, hd, rows, lens):
+    from zero_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    q = torch.randn(B, Hq * hd, generator=g).to(torch.bfloat16).to(DEV)
+    kc = torch.randn(B, rows, Hkv * hd, generator=g).to(torch.bfloat16).to(DEV)
+    vc = torch.randn(B, rows, Hkv * hd, generator=g).to(torch.bfloat16).to(DEV)
+    ln = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    out = ops.attn_decode(q, kc, vc, ln, max(lens), Hq, Hkv, hd, hd ** -0.5)
+    rep = Hq // Hkv
+    for b in range(B):
+        L = lens[b]
+        qf = q[b].float().view(Hq, hd)
+        kf = kc[b, :L].float().view(L, Hkv, hd).repeat_interleave(rep, dim=1)
+        vf = vc[b, :L].float().view(L, Hkv, hd).repeat_interleave(rep, dim=1)
+        p = torch.softmax(torch.einsum("hd,lhd->hl", qf, kf) * hd ** -0.5, dim=-1)
+        ref = torch.einsum("hl,lhd->hd", p, vf).reshape(-1)
+        assert maxrel(out[b], ref) < 8e-3, (b, L)
+
+
+def test_kv_cache_decode_matches_full_recompute():
+    """Prefill + 5 cached single-token steps on unit-scale random embeddings == the causal forward over
+    the whole grown sequence (HIP training path, and the fp32 oracle): catches cache / position bugs."""
+    from zero_amd.inference.decode import KVCache, forward_cached
+    spec = GOLDEN_CONFIGS["graft"]
+    params, cfg, model = _model(spec)
+    dec = spec["dec"]
+    g = torch.Generator(device="cpu").manual_seed(3)
+    B, S0, steps = 2, 37, 5
+    xs = torch.randn(B, S0 + steps, dec.hidden, generator=g).to(torch.bfloat16)
+    cache = KVCache(len(model.decoder.model.layers), B, S0 + steps, dec.kv_heads * dec.head_dim, DEV)
+    got = [forward_cached(model.decoder, xs[:, :S0].to(DEV), cache)[:, 0]]
+    for t in range(steps):
+        got.append(forward_cached(model.decoder, xs[:, S0 + t:S0 + t + 1].to(DEV), cache)[:, 0])
+    assert cache.length == S0 + steps
+    with torch.no_grad():
+        full = model.decoder(inputs_embeds=xs.to(DEV), use_cache=False)["logits"]
+    ref = zo.llama_forward(params, xs.float(), dec)
+    for t, lg in enumerate(got):
+        pos = S0 - 1 + t
+        assert maxrel(lg, full[:, pos]) <= 1e-2, t
+        assert maxrel(lg, ref[:, pos]) <= 2e-2, t
+
+
+def test_graft_generate_matches_golden(golden_dir):
+    from zero_amd.inference.vlm_infer import graft_generate, graft_inputs
+    spec = GOLDEN_CONFIGS["graft"]
+    gold = load_file(os.path.join(golden_dir, "graft.safetensors"))
+    params, cfg, model = _model(spec)
+    imgs, ids, _, img_id, _ = zo.synth_batch(spec["enc"], spec["dec"], **spec["batch"])
+    dimgs = [i.to(DEV).to(torch.bfloat16) for i in imgs]
+    x = graft_inputs(model, dimgs, ids, img_id)
+    assert tuple(x.shape) == (2, 6 + spec["enc"].tokens + 2 + 9, spec["dec"].hidden)
+    toks = graft_generate(model, dimgs, ids, img_id, max_new_tokens=spec["max_new_tokens"])
+    assert torch.equal(toks.cpu(), gold["fp32.gen_tokens"])
+    # the drop-in call of the reference (vlm_infer.py:264-270)
+    t2 = model.decoder.generate(inputs_embeds=x, attention_mask=torch.ones(x.shape[:2], device=DEV), do_sample=False,
+                                max_new_tokens=4, use_cache=True)
+    assert torch.equal(t2.cpu(), gold["fp32.gen_tokens"][:, :4])
+    # EOS: stop + pad
+    eos = int(gold["fp32.gen_tokens"][0, 0])
+    t3 = model.decoder.generate(inputs_embeds=x[:1], max_new_tokens=6, eos_token_id=eos, pad_token_id=3)
+    assert t3.shape[1] == 1 and int(t3[0, 0]) == eos
+
+
+def test_tensor_parallel_two_rank_threads():
+    """shard_llama_ + TPContext through the real layer code with W = 2 (rank threads + rendezvous
+    all-reduce on one device) against the unsharded decoder."""
+    from zero_amd.distributed.tensor_parallel import ThreadSimGroup, shard_llama_
+    from zero_amd.inference.decode import KVCache, forward_cached, generate
+    spec = GOLDEN_CONFIGS["graft"]
+    dec = spec["dec"]
+    g = torch.Generator(device="cpu").manual_seed(9)
+    B, S0 = 2, 29
+    xs = torch.randn(B, S0 + 2, dec.hidden, generator=g).to(torch.bfloat16).to(DEV)
+    _, _, base = _model(spec)
+    cache = KVCache(dec.layers, B, S0 + 2, dec.kv_heads * dec.head_dim, DEV)
+    want = [forward_cached(base.decoder, xs[:, :S0], cache)[:, 0], forward_cached(base.decoder, xs[:, S0:S0 + 1], cache)[:, 0]]
+    want_toks = generate(base.decoder, xs[:, :S0], max_new_tokens=5)
+    W = 2
+    group = ThreadSimGroup(W)
+    shards = []
+    for r in range(W):
+        _, _, m = _model(spec)
+        shard_llama_(m.decoder, r, W)
+        assert m.decoder.model.layers[0].self_attn.q_proj.weight.shape[0] == dec.heads // W * dec.head_dim
+        assert m.decoder.model.layers[0].mlp.down_proj.weight.shape[1] == dec.intermediate // W
+        shards.append(m.decoder)
+    results, errors = [None] * W, []
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            tp = group.context(r)
+            c = KVCache(dec.layers, B, S0 + 2, dec.kv_heads // W * dec.head_dim, DEV)
+            a = forward_cached(shards[r], xs[:, :S0], c, tp)[:, 0]
+            b = forward_cached(shards[r], xs[:, S0:S0 + 1], c, tp)[:, 0]
+            results[r] = (a, b, generate(shards[r], xs[:, :S0], max_new_tokens=5, tp=tp))
+        except Exception as e:      # a dead rank must not leave the other one waiting at the rendezvous
+            errors.append(e)
+            group._bar.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=100)
+    assert not errors, errors
+    for r in range(W):
+        a, b, toks = results[r]
+        assert maxrel(a, want[0]) <= 1.5e-2 and maxrel(b, want[1]) <= 1.5e-2, r
+        assert torch.equal(toks, want_toks), r
+    assert torch.equal(results[0][0], results[1][0])                  # every rank ends with the same logits

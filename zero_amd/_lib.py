@@ -27,6 +27,7 @@ SIGNATURES = {
     "zk_gemm_last_plan": [],
     "zk_attn_fwd": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "zk_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
+    "zk_attn_decode": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P],
     "zk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _L, _F, _P],
     "zk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P],
     "zk_rmsnorm_fwd": [_P, _P, _P, _P, _L, _L, _F, _P],

@@ -33,8 +33,8 @@ def load_hf_llama3(cfg: object):
         lcfg.rope_scaling = dict(rope_type="llama3", factor=factor, low_freq_factor=1.0, high_freq_factor=4.0,
                                  original_max_position_embeddings=8192)
     is_giant_model = lcfg.num_hidden_layers >= 80
-    if is_giant_model:
-        raise NotImplementedError("70B graft forward is a 'next' row (SURVEY.md §8f row 1)")
+    # (70B: the reference spreads it with device_map="balanced"; here one MI355X holds the 141 GB, and
+    #  distributed/tensor_parallel.shard_llama_ splits it 8 ways for the node — SURVEY.md §8f row 1)
     if getattr(cfg, "enable_lora", False):
         raise NotImplementedError("LoRA branch is out of scope (SURVEY.md §2 row 3)")
     model = LlamaForCausalLM(lcfg, device=getattr(cfg, "device", None))

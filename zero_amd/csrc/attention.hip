@@ -575,7 +575,100 @@ bool bad_attn(int64_t B, int64_t S, int64_t Hq, int64_t Hkv, int64_t hd, int64_t
   return false;
 }
 
+// =========================================================================================
+// Single-query attention over a KV cache (greedy decoding, tf generate(use_cache=True):
+// ref:inference/vlm_infer.py:259-270).  One block per (sequence, query head): HBM-bound byte work
+// (the cache rows are read once), no MFMA.  Pass 1: a thread per key, q broadcast from LDS, 16-byte
+// key loads -> scores in LDS, block max / sum; pass 2: a lane per feature pair, the 4 waves split
+// the keys, coalesced 4-byte loads across the lanes of a V row, partial sums merged through LDS.
+// =========================================================================================
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* q, const bf16_t* kc, const bf16_t* vc,
+                                                          bf16_t* out, const int* lens, int Hq, int Hkv, int ldq,
+                                                          int ldk, int ldv, int ldo, long long bsk, long long bsv,
+                                                          float scale) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  float* qs = dsm;                 // [HD]
+  float* red = dsm + HD;           // [4 * HD] (also the 4-entry block reductions)
+  float* sc = dsm + 5 * HD;        // [len]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / Hq, h = blockIdx.x % Hq;
+  const int kvh = h / (Hq / Hkv);
+  const int len = lens[b];
+  const bf16_t* kb = kc + (size_t)b * bsk + (size_t)kvh * HD;
+  const bf16_t* vb = vc + (size_t)b * bsv + (size_t)kvh * HD;
+  if (tid < HD) qs[tid] = bf2f(q[(size_t)b * ldq + (size_t)h * HD + tid]) * scale;
+  __syncthreads();
+  float mx = -3.0e38f;
+  for (int j = tid; j < len; j += 256) {
+    const bf16_t* kr = kb + (size_t)j * ldk;
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+      const u32x4 kv = *reinterpret_cast<const u32x4*>(kr + c * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dot += lo_bf(kv[e]) * qs[c * 8 + 2 * e] + hi_bf(kv[e]) * qs[c * 8 + 2 * e + 1];
+    }
+    sc[j] = dot;
+    mx = fmaxf(mx, dot);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = tid; j < len; j += 256) {
+    const float p = __expf(sc[j] - mx);
+    sc[j] = p;
+    sum += p;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  __syncthreads();
+  float a0 = 0.f, a1 = 0.f;
+  if (lane < HD / 2) {
+    for (int j = wave; j < len; j += 4) {
+      const unsigned int vv = *reinterpret_cast<const unsigned int*>(vb + (size_t)j * ldv + lane * 2);
+      const float p = sc[j];
+      a0 += p * lo_bf(vv);
+      a1 += p * hi_bf(vv);
+    }
+    red[wave * HD + lane * 2] = a0;
+    red[wave * HD + lane * 2 + 1] = a1;
+  }
+  __syncthreads();
+  if (tid < HD) {
+    const float v = (red[tid] + red[HD + tid] + red[2 * HD + tid] + red[3 * HD + tid]) * inv;
+    out[(size_t)b * ldo + (size_t)h * HD + tid] = f2bf(v);
+  }
+}
+
 }  // namespace
+
+extern "C" int zk_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out, const int* lens,
+                              int64_t B, int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk,
+                              int64_t ldv, int64_t ldo, int64_t batch_stride_k, int64_t batch_stride_v,
+                              int64_t max_len, float scale, hipStream_t stream) {
+  if (!q || !k_cache || !v_cache || !out || !lens || B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv) return ZK_EINVAL;
+  if ((head_dim != 64 && head_dim != 128) || ((ldk | ldv) & 7) || max_len <= 0 || max_len > 15000) return ZK_EINVAL;   // scores live in <= 64 KiB of LDS
+  if ((reinterpret_cast<uintptr_t>(k_cache) | reinterpret_cast<uintptr_t>(v_cache)) & 15) return ZK_EINVAL;
+  if ((batch_stride_k | batch_stride_v) & 7) return ZK_EINVAL;
+  const size_t smem = (size_t)(5 * head_dim + max_len) * sizeof(float);
+  dim3 grid((unsigned)(B * Hq)), block(256);
+  if (head_dim == 128)
+    hipLaunchKernelGGL((attn_decode_kernel<128>), grid, block, smem, stream, (const bf16_t*)q, (const bf16_t*)k_cache,
+                       (const bf16_t*)v_cache, (bf16_t*)out, lens, (int)Hq, (int)Hkv, (int)ldq, (int)ldk, (int)ldv,
+                       (int)ldo, (long long)batch_stride_k, (long long)batch_stride_v, scale);
+  else
+    hipLaunchKernelGGL((attn_decode_kernel<64>), grid, block, smem, stream, (const bf16_t*)q, (const bf16_t*)k_cache,
+                       (const bf16_t*)v_cache, (bf16_t*)out, lens, (int)Hq, (int)Hkv, (int)ldq, (int)ldk, (int)ldv,
+                       (int)ldo, (long long)batch_stride_k, (long long)batch_stride_v, scale);
+  ZK_CHECK_LAUNCH();
+  return ZK_OK;
+}
 
 extern "C" int zk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B, int64_t S,
                            int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv,

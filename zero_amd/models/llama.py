@@ -167,13 +167,22 @@ class LlamaForCausalLM(nn.Module):
             self.lm_head.weight = self.model.embed_tokens.weight            # tf:llama:422
         for p in self.parameters():
             p.requires_grad = False                                         # frozen surrogate (see module docstring)
+        import types
+        self.generation_config = types.SimpleNamespace(pad_token_id=None, eos_token_id=None)   # ref:vlm_infer.py:213
 
     def get_input_embeddings(self):
         return self.model.embed_tokens
 
+    def generate(self, inputs_embeds=None, attention_mask=None, do_sample=False, max_new_tokens=20,
+                 use_cache=True, **kwargs):
+        """Greedy decoding with a KV cache (ref:inference/vlm_infer.py:259-270); new token ids only."""
+        from ..inference.decode import generate
+        return generate(self, inputs_embeds, attention_mask=attention_mask, do_sample=do_sample,
+                        max_new_tokens=max_new_tokens, use_cache=use_cache, **kwargs)
+
     def forward(self, input_ids=None, inputs_embeds=None, use_cache=False, **kwargs):
         if use_cache:
-            raise NotImplementedError("KV-cache decoding is outside the training hot path (SURVEY.md §8f row 1)")
+            raise NotImplementedError("forward(use_cache=True): use .generate() / inference.decode.forward_cached")
         h = self.model(input_ids=input_ids, inputs_embeds=inputs_embeds)
         logits = ZF.LinearFn.apply(h, self.lm_head.weight, None, ops.EPI_NONE)
         return CausalLMOutput(logits=logits)

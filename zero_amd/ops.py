@@ -35,6 +35,12 @@ def _chk2d(t: torch.Tensor, name: str, dtype=BF16):
         raise ValueError(f"{name}: expected a 2-D row-major view, got shape {tuple(t.shape)} strides {t.stride()}")
 
 
+def _ld(t: torch.Tensor) -> int:
+    """Leading dimension of a 2-D row-major view; a single row may carry any stride (torch keeps the
+    parent's), so its own width is reported instead."""
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
 def _chk_flat(t: torch.Tensor, name: str, dtype=BF16):
     if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
         raise ValueError(f"{name}: expected a contiguous {dtype} ROCm tensor")
@@ -77,20 +83,20 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
         _chk2d(residual, "residual")
         if residual.shape != (M, N):
             raise ValueError("gemm: residual shape")
-        ldr = residual.stride(0)
+        ldr = _ld(residual)
     if aux_out is not None:
         _chk2d(aux_out, "aux_out")
-        if aux_out.shape != (M, N) or aux_out.stride(0) != out.stride(0):
+        if aux_out.shape != (M, N) or _ld(aux_out) != _ld(out):
             raise ValueError("gemm: aux_out must match out's shape and row stride")
     ldaux = 0
     if aux_in is not None:
         _chk2d(aux_in, "aux_in")
         if aux_in.shape != (M, N):
             raise ValueError("gemm: aux_in shape")
-        ldaux = aux_in.stride(0)
+        ldaux = _ld(aux_in)
     if alpha_dev is not None:
         _chk_flat(alpha_dev, "alpha_dev", torch.float32)
-    rc = lib.zk_gemm_bf16(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+    rc = lib.zk_gemm_bf16(_p(a), _p(b), _p(out), M, N, K, _ld(a), _ld(b), _ld(out),
                           int(trans_a), int(trans_b), epilogue, _p(bias), _p(residual), ldr, _p(aux_out),
                           _p(aux_in), ldaux, float(alpha), _p(alpha_dev), int(accumulate),
                           _workspace(a.device).data_ptr(), WORKSPACE_BYTES, _stream())
@@ -117,8 +123,8 @@ def gemm_swiglu(x: torch.Tensor, wgu_i: torch.Tensor):
         raise ValueError("gemm_swiglu: shapes")
     gu = torch.empty((M, N), dtype=BF16, device=x.device)
     h = torch.empty((M, N // 2), dtype=BF16, device=x.device)
-    rc = lib.zk_gemm_bf16(_p(x), _p(wgu_i), _p(gu), M, N, K, x.stride(0), wgu_i.stride(0), gu.stride(0), 0, 0,
-                          EPI_SWIGLU, None, None, 0, _p(h), None, h.stride(0), 1.0, None, 0,
+    rc = lib.zk_gemm_bf16(_p(x), _p(wgu_i), _p(gu), M, N, K, _ld(x), _ld(wgu_i), _ld(gu), 0, 0,
+                          EPI_SWIGLU, None, None, 0, _p(h), None, _ld(h), 1.0, None, 0,
                           _workspace(x.device).data_ptr(), WORKSPACE_BYTES, _stream())
     check(rc, f"zk_gemm_bf16(SWIGLU) M={M} N={N} K={K}")
     return gu, h
@@ -170,6 +176,24 @@ def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B: int, S: int, Hq: int, Hkv: int
                          Hkv, hd, q.stride(0), k.stride(0), v.stride(0), o.stride(0), dq.stride(0), dk.stride(0),
                          dv.stride(0), float(scale), int(causal), _stream())
     check(rc, "zk_attn_bwd")
+
+
+def attn_decode(q, k_cache, v_cache, lens_i32, max_len: int, Hq: int, Hkv: int, hd: int, scale: float, out=None):
+    """One query per sequence over a KV cache.  q: [B, Hq*hd]; caches: [B, rows, Hkv*hd] (contiguous
+    last dim); lens_i32: int32 [B] valid rows per sequence (<= max_len <= rows)."""
+    _chk2d(q, "q")
+    B = q.shape[0]
+    for t, n in ((k_cache, "k_cache"), (v_cache, "v_cache")):
+        if t.dtype != BF16 or t.dim() != 3 or t.stride(2) != 1 or t.shape[0] != B or t.shape[2] != Hkv * hd:
+            raise ValueError(f"attn_decode: {n} must be bf16 [B, rows, Hkv*hd]")
+    if lens_i32.dtype != torch.int32 or lens_i32.numel() != B or max_len > k_cache.shape[1]:
+        raise ValueError("attn_decode: lens must be int32 [B] and max_len within the cache")
+    if out is None:
+        out = torch.empty((B, Hq * hd), dtype=BF16, device=q.device)
+    check(lib.zk_attn_decode(_p(q), _p(k_cache), _p(v_cache), _p(out), _p(lens_i32), B, Hq, Hkv, hd, q.stride(0),
+                             k_cache.stride(1), v_cache.stride(1), out.stride(0), k_cache.stride(0), v_cache.stride(0),
+                             int(max_len), float(scale), _stream()), "zk_attn_decode")
+    return out
 
 
 def layernorm_fwd(x, gamma, beta, eps: float, save_stats: bool = True):
