@@ -71,6 +71,13 @@ int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, in
                  const void* aux_in, int64_t ldaux, float alpha, const float* alpha_dev,
                  int accumulate, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
+/* Skinny product for decoding: y[M][N] = x[M][K] W[N][K]^T (+ residual[M][N]), M <= 4 rows, fp32
+ * accumulate.  The same F.linear call sites (tf:llama:174-176,230-241,280,480) as they occur in the
+ * single-token steps of greedy decoding (ref:inference/vlm_infer.py:259-270): HBM-bound, every weight
+ * byte is read once per token. */
+int zk_gemv_bf16(const void* x, const void* W, void* y, int64_t M, int64_t N, int64_t K, int64_t ldx,
+                 int64_t ldw, int64_t ldy, const void* residual, int64_t ldr, hipStream_t stream);
+
 /* Tuning hook (no counterpart in the reference): force the block tile of zk_gemm_bf16.
  * -1 = built-in cost model (default), 0 = 128x128, 1 = 256x128, 2 = 256x256;
  * 10/11 = LDS-DMA for all operands / registers for transposed ones (default);
@@ -117,6 +124,29 @@ int zk_attn_decode(const void* q, const void* k_cache, const void* v_cache, void
                    const int* lens, int64_t B, int64_t Hq, int64_t Hkv, int64_t head_dim,
                    int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t batch_stride_k,
                    int64_t batch_stride_v, int64_t max_len, float scale, hipStream_t stream);
+
+/* One Llama decoder layer on a single-token decoding step, enqueued natively in two halves so a
+ * tensor-parallel host can all-reduce the partial sums between them (tf:llama:295-324 with a KV cache;
+ * ref:inference/vlm_infer.py:259-270).  Head counts and F are the LOCAL (sharded) ones; wqkv / wgu are
+ * the packed q|k|v and gate|up weights ([rows][d], k contiguous); the caches are
+ * [B][cache_rows][nkv*hd]; lens (device int32 [B]) must hold pos + 1; h / qkv / ao / gu / hm are
+ * caller-owned scratch rows ([B][d], [B][(nh+2nkv)hd], [B][nh*hd], [B][2F], [B][F]).
+ *   attn: out = (add_residual ? x : 0) + o_proj(attention(rope(qkv(rmsnorm(x)))))   and appends k, v
+ *   mlp : out = (add_residual ? xa : 0) + down(silu(gate(rmsnorm(xa))) * up(rmsnorm(xa)))
+ * B <= 4.  Allocates nothing, never synchronises. */
+typedef struct {
+  int64_t B, d, nh, nkv, hd, F, cache_rows, pos;
+  float eps;
+  const void *ln1_w, *wqkv, *wo, *ln2_w, *wgu, *wdown;
+  const float *cos_t, *sin_t;
+  void *k_cache, *v_cache;
+  const int* lens;
+  void *h, *qkv, *ao, *gu, *hm;
+} zk_decode_layer_t;
+int zk_llama_decode_attn(const zk_decode_layer_t* L, const void* x, void* out, int add_residual,
+                         hipStream_t stream);
+int zk_llama_decode_mlp(const zk_decode_layer_t* L, const void* xa, void* out, int add_residual,
+                        hipStream_t stream);
 
 /* ---- LayerNorm (tf:clip:358-360,370,379,605,642; ref:adapter.py:94) ------------------
  * y = (x - mean) * rstd * gamma + beta over the last dim D (<= 8192, multiple of 8),

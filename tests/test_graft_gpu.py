@@ -52,10 +52,13 @@ def test_attn_decode_kernel(B, Hq, Hkv, hd, rows, lens):
         assert maxrel(out[b], ref) < 8e-3, (b, L)
 
 
-def test_kv_cache_decode_matches_full_recompute():
+@pytest.mark.parametrize("native", [True, False], ids=["native-layer-driver", "python-launches"])
+def test_kv_cache_decode_matches_full_recompute(native, monkeypatch):
     """Prefill + 5 cached single-token steps on unit-scale random embeddings == the causal forward over
     the whole grown sequence (HIP training path, and the fp32 oracle): catches cache / position bugs."""
+    from zero_amd.inference import decode
     from zero_amd.inference.decode import KVCache, forward_cached
+    monkeypatch.setattr(decode, "USE_NATIVE_DECODE", native)
     spec = GOLDEN_CONFIGS["graft"]
     params, cfg, model = _model(spec)
     dec = spec["dec"]
@@ -66,7 +69,7 @@ def test_kv_cache_decode_matches_full_recompute():
     got = [forward_cached(model.decoder, xs[:, :S0].to(DEV), cache)[:, 0]]
     for t in range(steps):
         got.append(forward_cached(model.decoder, xs[:, S0 + t:S0 + t + 1].to(DEV), cache)[:, 0])
-    assert cache.length == S0 + steps
+    assert cache.length == S0 + steps and (getattr(cache, "_plan", None) is not None) == native
     with torch.no_grad():
         full = model.decoder(inputs_embeds=xs.to(DEV), use_cache=False)["logits"]
     ref = zo.llama_forward(params, xs.float(), dec)

@@ -213,6 +213,26 @@ def test_gemm_persistent_ring_swiglu(M, F, K):
     assert torch.equal(blk[:, :, 0].reshape(M, F), dgu_ref[:, :F]) and torch.equal(blk[:, :, 1].reshape(M, F), dgu_ref[:, F:])
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("N,K", [(1280, 8192), (8192, 1024), (8192, 3584), (4099 * 8, 264), (72, 40)])
+def test_gemv_decode_rows(M, N, K):
+    """M <= 4 rows take the weight-streaming kernel (ops.gemm dispatch); with and without residual,
+    strided x rows, against fp32."""
+    buf = rnd(M, K + 64, seed=81)
+    x = buf[:, 32:32 + K] if K % 8 == 0 and M > 1 else rnd(M, K, seed=81)
+    w, res = rnd(N, K, seed=82, scale=0.3), rnd(M, N, seed=83)
+    ref = x.float() @ w.float().t()
+    y = ops.gemm(x, w)
+    assert relerr(y, ref) < 6e-3
+    y2 = ops.gemm(x, w, residual=res)
+    assert relerr(y2, ref.to(torch.bfloat16).float() + res.float()) < 6e-3
+    old, ops.GEMV_MAX_ROWS = ops.GEMV_MAX_ROWS, 0          # the MFMA path on the same rows agrees
+    try:
+        assert relerr(ops.gemm(x.contiguous(), w), ref) < 6e-3
+    finally:
+        ops.GEMV_MAX_ROWS = old
+
+
 @pytest.mark.parametrize("splits", [100, 102, 105, 116])
 def test_gemm_split_k(splits):
     """Small output + long contraction: fp32 slabs per split + finishing pass (wgrad / lm_head dgrad)."""

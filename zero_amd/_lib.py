@@ -23,11 +23,14 @@ _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "zk_abi_version": [],
     "zk_gemm_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _P, _P, _L, _P, _P, _L, _F, _P, _I, _P, _L, _P],
+    "zk_gemv_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _P, _L, _P],
     "zk_gemm_set_tile": [_I],
     "zk_gemm_last_plan": [],
     "zk_attn_fwd": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "zk_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "zk_attn_decode": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P],
+    "zk_llama_decode_attn": [_P, _P, _P, _I, _P],
+    "zk_llama_decode_mlp": [_P, _P, _P, _I, _P],
     "zk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _L, _F, _P],
     "zk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P],
     "zk_rmsnorm_fwd": [_P, _P, _P, _P, _L, _L, _F, _P],
@@ -56,6 +59,13 @@ for _name, _args in SIGNATURES.items():
 ABI_VERSION = 1
 if lib.zk_abi_version() != ABI_VERSION:
     raise ImportError("libzero_hip.so ABI version mismatch; rebuild with `make -C zero_amd/csrc`")
+
+
+class DecodeLayer(ctypes.Structure):
+    """zk_decode_layer_t of include/zero_hip.h."""
+    _fields_ = ([(n, c_int64) for n in ("B", "d", "nh", "nkv", "hd", "F", "cache_rows", "pos")] + [("eps", c_float)] +
+                [(n, c_void_p) for n in ("ln1_w", "wqkv", "wo", "ln2_w", "wgu", "wdown", "cos_t", "sin_t", "k_cache",
+                                         "v_cache", "lens", "h", "qkv", "ao", "gu", "hm")])
 
 
 class ZeroHipError(RuntimeError):

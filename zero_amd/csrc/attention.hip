@@ -579,8 +579,8 @@ bool bad_attn(int64_t B, int64_t S, int64_t Hq, int64_t Hkv, int64_t hd, int64_t
 // Single-query attention over a KV cache (greedy decoding, tf generate(use_cache=True):
 // ref:inference/vlm_infer.py:259-270).  One block per (sequence, query head): HBM-bound byte work
 // (the cache rows are read once), no MFMA.  Pass 1: a thread per key, q broadcast from LDS, 16-byte
-// key loads -> scores in LDS, block max / sum; pass 2: a lane per feature pair, the 4 waves split
-// the keys, coalesced 4-byte loads across the lanes of a V row, partial sums merged through LDS.
+// key loads -> scores in LDS, block max / sum; pass 2: 16-byte V loads, a wave covers 64/(hd/8) keys per
+// instruction, partial sums merged by lane shuffles and through LDS.
 // =========================================================================================
 template <int HD>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* q, const bf16_t* kc, const bf16_t* vc,
@@ -628,16 +628,26 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* q, const
   __syncthreads();
   const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
   __syncthreads();
-  float a0 = 0.f, a1 = 0.f;
-  if (lane < HD / 2) {
-    for (int j = wave; j < len; j += 4) {
-      const unsigned int vv = *reinterpret_cast<const unsigned int*>(vb + (size_t)j * ldv + lane * 2);
-      const float p = sc[j];
-      a0 += p * lo_bf(vv);
-      a1 += p * hi_bf(vv);
-    }
-    red[wave * HD + lane * 2] = a0;
-    red[wave * HD + lane * 2 + 1] = a1;
+  // pass 2: LPR = HD/8 lanes cover one V row with 16-byte loads, so a wave takes 64/LPR keys per
+  // instruction and the block 4x that; the loads of 4 steps are in flight together
+  constexpr int LPR = HD / 8, KS = 64 / LPR;
+  const int dch = lane % LPR, ks = lane / LPR;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int j = wave * KS + ks; j < len; j += 4 * KS) {
+    const u32x4 vv = *reinterpret_cast<const u32x4*>(vb + (size_t)j * ldv + dch * 8);
+    const float p = sc[j];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[2 * e] += p * lo_bf(vv[e]); acc[2 * e + 1] += p * hi_bf(vv[e]); }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+  }
+  if (lane < LPR) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave * HD + dch * 8 + e] = acc[e];
   }
   __syncthreads();
   if (tid < HD) {

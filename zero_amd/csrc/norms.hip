@@ -289,6 +289,34 @@ __global__ __launch_bounds__(256) void rmsnorm_dweight_kernel(const bf16_t* dy, 
   }
 }
 
+// A handful of rows (single-token decoding steps): one 256-thread block per row, same arithmetic.
+__global__ __launch_bounds__(256) void rmsnorm_fwd_block_kernel(const bf16_t* x, const bf16_t* w, bf16_t* y,
+                                                                float* rstd_o, int D, float eps) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x, nv = D >> 3;
+  const bf16_t* xr = x + (size_t)row * D;
+  float s = 0.f;
+  for (int i = tid; i < nv; i += 256) {
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4*>(xr + (size_t)i * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += f[j] * f[j];
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)D + eps);
+  if (tid == 0 && rstd_o) rstd_o[row] = rstd;
+  for (int i = tid; i < nv; i += 256) {
+    float f[8], ww[8];
+    unpack8(*reinterpret_cast<const u32x4*>(xr + (size_t)i * 8), f);
+    unpack8(*reinterpret_cast<const u32x4*>(w + (size_t)i * 8), ww);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = ww[j] * bf2f(f2bf(f[j] * rstd));
+    *reinterpret_cast<u32x4*>(y + (size_t)row * D + (size_t)i * 8) = pack8(f);
+  }
+}
+
 inline bool bad_dim(int64_t rows, int64_t D) { return rows <= 0 || D <= 0 || (D & 7) || D > 8192 || rows > 0x7FFFFFFF; }
 
 }  // namespace
@@ -329,6 +357,12 @@ extern "C" int zk_layernorm_bwd(const void* dy, const void* x, const void* gamma
 extern "C" int zk_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t D, float eps,
                               hipStream_t stream) {
   if (!x || !w || !y || bad_dim(rows, D)) return ZK_EINVAL;
+  if (rows <= 16) {   // decoding: a block per row instead of a single wave per row
+    hipLaunchKernelGGL(rmsnorm_fwd_block_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const bf16_t*)x,
+                       (const bf16_t*)w, (bf16_t*)y, rstd, (int)D, eps);
+    ZK_CHECK_LAUNCH();
+    return ZK_OK;
+  }
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
 #define CALL(V) hipLaunchKernelGGL((rmsnorm_fwd_kernel<V>), grid, block, 0, stream, (const bf16_t*)x, \
     (const bf16_t*)w, (bf16_t*)y, rstd, (int)rows, (int)D, eps)

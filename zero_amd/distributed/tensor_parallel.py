@@ -87,5 +87,6 @@ class ThreadSimGroup:
                 total = total + t.float()
             out = total.to(part.dtype)
             self._bar.wait()                     # nobody overwrites a slot before everyone has summed
-            return out
+            part.copy_(out)                      # in place, like dist.all_reduce
+            return part
         return TPContext(rank, self.world, reduce_fn=reduce)

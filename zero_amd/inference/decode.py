@@ -18,6 +18,7 @@ from .. import ops
 from ..distributed.tensor_parallel import TPContext
 
 BF16 = torch.bfloat16
+USE_NATIVE_DECODE = True     # single-token steps through the C layer drivers (False: kernel by kernel from Python)
 
 
 class KVCache:
@@ -73,7 +74,11 @@ def layer_infer(layer, x2: torch.Tensor, B: int, S: int, pos0: int, cos_t, sin_t
     xa = tp.reduce(ops.gemm(ao, a.o_proj.weight.detach(), residual=x2 if tp.lead else None))
     h2, _ = ops.rmsnorm_fwd(xa, layer.post_attention_layernorm.weight, eps, save_stats=False)
     gw, uw = m.gate_proj.weight, m.up_proj.weight
-    if gw.shape[0] % 32 == 0:
+    wgu = ZF.packed_rows(gw, uw)
+    if M <= ops.GEMV_MAX_ROWS and wgu is not None:
+        # decoding: stream the packed gate|up weight once (GEMV), then the small SwiGLU kernel
+        hm = ops.swiglu_fwd(ops.gemm(h2, wgu.detach()), gw.shape[0])
+    elif gw.shape[0] % 32 == 0:
         _, hm = ops.gemm_swiglu(h2, _gate_up_interleaved(gw, uw))
     else:
         F = gw.shape[0]
@@ -82,6 +87,72 @@ def layer_infer(layer, x2: torch.Tensor, B: int, S: int, pos0: int, cos_t, sin_t
         ops.gemm(h2, uw.detach(), out=gu[:, F:])
         hm = ops.swiglu_fwd(gu, F)
     return tp.reduce(ops.gemm(hm, m.down_proj.weight.detach(), residual=xa if tp.lead else None))
+
+
+class DecodePlan:
+    """Single-token steps through the native layer drivers (zk_llama_decode_attn / _mlp): one
+    zk_decode_layer_t per layer (weights, cache, scratch rows: pointers that stay put for the whole
+    generation), built once per cache.  Needs packed q|k|v and gate|up weights and B <= 4."""
+
+    def __init__(self, decoder, cache: KVCache, cos_t, sin_t):
+        import ctypes
+        from .._lib import DecodeLayer
+        model = decoder.model
+        layers = model.layers[: decoder.config.num_hidden_layers]
+        l0 = layers[0]
+        _, _, hd, eps = l0.cfg_dims
+        a0, m0 = l0.self_attn, l0.mlp
+        B = cache.k[0].shape[0]
+        d = a0.q_proj.weight.shape[1]
+        nh, nkv, F = a0.q_proj.weight.shape[0] // hd, a0.k_proj.weight.shape[0] // hd, m0.gate_proj.weight.shape[0]
+        dev = cache.k[0].device
+        mk = lambda n: torch.empty((B, n), dtype=BF16, device=dev)
+        self.scratch = [mk(d), mk((nh + 2 * nkv) * hd), mk(nh * hd), mk(2 * F), mk(F)]
+        self.bufs = [mk(d), mk(d), mk(d)]                 # layer input / attention-half output / layer output
+        self.keep = []                                    # views the structs point into
+        self.structs = []
+        for li, layer in enumerate(layers):
+            a, m = layer.self_attn, layer.mlp
+            wqkv = ZF.packed_rows(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight)
+            wgu = ZF.packed_rows(m.gate_proj.weight, m.up_proj.weight)
+            if wqkv is None or wgu is None:
+                raise ValueError("DecodePlan needs packed q|k|v and gate|up weights")
+            self.keep += [wqkv, wgu]
+            st = DecodeLayer(B=B, d=d, nh=nh, nkv=nkv, hd=hd, F=F, cache_rows=cache.max_len, pos=0, eps=eps,
+                             ln1_w=layer.input_layernorm.weight.data_ptr(), wqkv=wqkv.data_ptr(),
+                             wo=a.o_proj.weight.data_ptr(), ln2_w=layer.post_attention_layernorm.weight.data_ptr(),
+                             wgu=wgu.data_ptr(), wdown=m.down_proj.weight.data_ptr(), cos_t=cos_t.data_ptr(),
+                             sin_t=sin_t.data_ptr(), k_cache=cache.k[li].data_ptr(), v_cache=cache.v[li].data_ptr(),
+                             lens=cache.lens.data_ptr(), h=self.scratch[0].data_ptr(), qkv=self.scratch[1].data_ptr(),
+                             ao=self.scratch[2].data_ptr(), gu=self.scratch[3].data_ptr(), hm=self.scratch[4].data_ptr())
+            self.structs.append(st)
+        self._byref = [ctypes.byref(s_) for s_ in self.structs]
+
+    @staticmethod
+    def usable(decoder, B: int) -> bool:
+        l0 = decoder.model.layers[0]
+        a, m = l0.self_attn, l0.mlp
+        return (B <= 4 and ZF.packed_rows(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight) is not None
+                and ZF.packed_rows(m.gate_proj.weight, m.up_proj.weight) is not None
+                and a.o_proj.weight.is_contiguous() and m.down_proj.weight.is_contiguous())
+
+    def step(self, x2: torch.Tensor, pos: int, tp: TPContext) -> torch.Tensor:
+        from .._lib import check, lib
+        stream = torch.cuda.current_stream().cuda_stream
+        cur, mid, nxt = self.bufs
+        cur.copy_(x2)
+        lead = int(tp.lead)
+        for st, ref in zip(self.structs, self._byref):
+            st.pos = pos
+            check(lib.zk_llama_decode_attn(ref, cur.data_ptr(), mid.data_ptr(), lead, stream), "zk_llama_decode_attn")
+            if tp.world > 1:
+                tp.reduce(mid)
+            check(lib.zk_llama_decode_mlp(ref, mid.data_ptr(), nxt.data_ptr(), lead, stream), "zk_llama_decode_mlp")
+            if tp.world > 1:
+                tp.reduce(nxt)
+            cur, nxt = nxt, cur
+        self.bufs = [cur, mid, nxt]
+        return cur
 
 
 @torch.no_grad()
@@ -97,8 +168,14 @@ def forward_cached(decoder, x: torch.Tensor, cache: KVCache, tp: Optional[TPCont
     cos_t, sin_t = model.rotary_emb.tables(cache.max_len, x.device)
     cache.lens.fill_(pos0 + S)
     h = x.reshape(B * S, d).to(BF16).contiguous()
-    for li, layer in enumerate(model.layers[: decoder.config.num_hidden_layers]):
-        h = layer_infer(layer, h, B, S, pos0, cos_t, sin_t, cache, li, tp)
+    if S == 1 and USE_NATIVE_DECODE and DecodePlan.usable(decoder, B):
+        plan = getattr(cache, "_plan", None)
+        if plan is None:
+            plan = cache._plan = DecodePlan(decoder, cache, cos_t, sin_t)
+        h = plan.step(h, pos0, tp)
+    else:
+        for li, layer in enumerate(model.layers[: decoder.config.num_hidden_layers]):
+            h = layer_infer(layer, h, B, S, pos0, cos_t, sin_t, cache, li, tp)
     cache.length = pos0 + S
     if last_only:
         h = h.view(B, S, d)[:, -1].clone(memory_format=torch.contiguous_format)

@@ -46,6 +46,7 @@ def _chk_flat(t: torch.Tensor, name: str, dtype=BF16):
         raise ValueError(f"{name}: expected a contiguous {dtype} ROCm tensor")
 
 
+GEMV_MAX_ROWS = 4        # products with at most this many rows go to the weight-streaming kernel
 _WORKSPACE = {}
 WORKSPACE_BYTES = 160 << 20
 
@@ -96,6 +97,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
         ldaux = _ld(aux_in)
     if alpha_dev is not None:
         _chk_flat(alpha_dev, "alpha_dev", torch.float32)
+    if (M <= GEMV_MAX_ROWS and not trans_a and not trans_b and epilogue == EPI_NONE and bias is None and aux_out is None
+            and alpha_dev is None and alpha == 1.0 and not accumulate):
+        # decode-time product: stream the weight once (zk_gemv_bf16) instead of a 128-row MFMA tile
+        rc = lib.zk_gemv_bf16(_p(a), _p(b), _p(out), M, N, K, _ld(a), _ld(b), _ld(out), _p(residual), ldr, _stream())
+        check(rc, f"zk_gemv_bf16 M={M} N={N} K={K}")
+        return out
     rc = lib.zk_gemm_bf16(_p(a), _p(b), _p(out), M, N, K, _ld(a), _ld(b), _ld(out),
                           int(trans_a), int(trans_b), epilogue, _p(bias), _p(residual), ldr, _p(aux_out),
                           _p(aux_in), ldaux, float(alpha), _p(alpha_dev), int(accumulate),
