@@ -77,6 +77,12 @@ int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, in
  * byte is read once per token. */
 int zk_gemv_bf16(const void* x, const void* W, void* y, int64_t M, int64_t N, int64_t K, int64_t ldx,
                  int64_t ldw, int64_t ldy, const void* residual, int64_t ldr, hipStream_t stream);
+/* The same with the x operand produced on the fly: xmode 1 = RMSNorm of x with weight
+ * ln_w / eps (tf:llama:62-67, same roundings as zk_rmsnorm_fwd), xmode 2 = SwiGLU of a packed
+ * gate|up row (x[k] = bf16(bf16(silu(xin[k])) * xin[K + k]), tf:llama:175; ldx >= 2K), 0 = plain. */
+int zk_gemv_fused_bf16(const void* x, const void* W, void* y, int64_t M, int64_t N, int64_t K,
+                       int64_t ldx, int64_t ldw, int64_t ldy, const void* residual, int64_t ldr,
+                       int xmode, const void* ln_w, float eps, hipStream_t stream);
 
 /* Tuning hook (no counterpart in the reference): force the block tile of zk_gemm_bf16.
  * -1 = built-in cost model (default), 0 = 128x128, 1 = 256x128, 2 = 256x256;

@@ -233,6 +233,21 @@ def test_gemv_decode_rows(M, N, K):
         ops.GEMV_MAX_ROWS = old
 
 
+@pytest.mark.parametrize("M", [1, 3, 4])
+def test_gemv_fused_operands_bit_identical(M):
+    """RMSNorm / SwiGLU made inside the decode product == the separate kernels followed by the plain product."""
+    d, N, F = 8192, 1280, 3584
+    x, lnw, w = rnd(M, d, seed=91), rnd(d, seed=92), rnd(N, d, seed=93, scale=0.05)
+    h, _ = ops.rmsnorm_fwd(x, lnw, 1e-5)
+    assert torch.equal(ops.gemv_fused(x, w, xmode=1, ln_w=lnw, eps=1e-5), ops.gemm(h, w))
+    gu, wd, res = rnd(M, 2 * F, seed=94), rnd(d, F, seed=95, scale=0.05), rnd(M, d, seed=96)
+    hm = ops.swiglu_fwd(gu, F)
+    assert torch.equal(ops.gemv_fused(gu, wd, xmode=2, residual=res), ops.gemm(hm, wd, residual=res))
+    x2, lnw2, w2 = rnd(M, 264, seed=97), rnd(264, seed=98), rnd(72, 264, seed=99)       # ragged K / N
+    h2, _ = ops.rmsnorm_fwd(x2, lnw2, 1e-5)
+    assert torch.equal(ops.gemv_fused(x2, w2, xmode=1, ln_w=lnw2, eps=1e-5), ops.gemm(h2, w2))
+
+
 @pytest.mark.parametrize("splits", [100, 102, 105, 116])
 def test_gemm_split_k(splits):
     """Small output + long contraction: fp32 slabs per split + finishing pass (wgrad / lm_head dgrad)."""

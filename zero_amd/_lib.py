@@ -24,6 +24,7 @@ SIGNATURES = {
     "zk_abi_version": [],
     "zk_gemm_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _P, _P, _L, _P, _P, _L, _F, _P, _I, _P, _L, _P],
     "zk_gemv_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _P, _L, _P],
+    "zk_gemv_fused_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _P, _L, _I, _P, _F, _P],
     "zk_gemm_set_tile": [_I],
     "zk_gemm_last_plan": [],
     "zk_attn_fwd": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],

@@ -6,8 +6,8 @@
 // the attention half up to the o-projection partial sum, the MLP half up to the down-projection
 // partial sum — so that a tensor-parallel host can all-reduce between them (2 per layer), and a
 // single-GPU host pays two calls per layer instead of twelve.  Nothing is allocated: the caller owns
-// the scratch rows.  All kernels are the library's own (zk_rmsnorm_fwd, zk_gemv_bf16, zk_rope,
-// zk_attn_decode, zk_swiglu_fwd) plus the cache append below.
+// the scratch rows.  All kernels are the library's own (zk_gemv_fused_bf16 with the RMSNorm / SwiGLU
+// operand modes, zk_rope, zk_attn_decode) plus the cache append below.
 #include "common.h"
 #include "../../include/zero_hip.h"
 
@@ -40,8 +40,8 @@ extern "C" int zk_llama_decode_attn(const zk_decode_layer_t* L, const void* x, v
                                     hipStream_t stream) {
   if (bad_layer(L) || !x || !out) return ZK_EINVAL;
   const int64_t B = L->B, d = L->d, hd = L->hd, qw = L->nh * hd, kvw = L->nkv * hd, W = qw + 2 * kvw;
-  ZK_TRY(zk_rmsnorm_fwd(x, L->ln1_w, L->h, nullptr, B, d, L->eps, stream));
-  ZK_TRY(zk_gemv_bf16(L->h, L->wqkv, L->qkv, B, W, d, d, d, W, nullptr, 0, stream));
+  // RMSNorm fused into the q|k|v product (d > 16384 would need the separate kernel: not a Llama shape)
+  ZK_TRY(zk_gemv_fused_bf16(x, L->wqkv, L->qkv, B, W, d, d, d, W, nullptr, 0, 1, L->ln1_w, L->eps, stream));
   // every row is position `pos`: a one-row table (S = 1) starting at that position
   ZK_TRY(zk_rope(L->qkv, L->cos_t + L->pos * (hd / 2), L->sin_t + L->pos * (hd / 2), B, 1, L->nh + L->nkv, hd, W, 0,
                  stream));
@@ -59,8 +59,8 @@ extern "C" int zk_llama_decode_mlp(const zk_decode_layer_t* L, const void* xa, v
                                    hipStream_t stream) {
   if (bad_layer(L) || !xa || !out) return ZK_EINVAL;
   const int64_t B = L->B, d = L->d, F = L->F;
-  ZK_TRY(zk_rmsnorm_fwd(xa, L->ln2_w, L->h, nullptr, B, d, L->eps, stream));
-  ZK_TRY(zk_gemv_bf16(L->h, L->wgu, L->gu, B, 2 * F, d, d, d, 2 * F, nullptr, 0, stream));
-  ZK_TRY(zk_swiglu_fwd(L->gu, L->hm, B, F, stream));
-  return zk_gemv_bf16(L->hm, L->wdown, out, B, d, F, F, F, d, add_residual ? xa : nullptr, d, stream);
+  // RMSNorm fused into the gate|up product, SwiGLU fused into the down product's x operand
+  ZK_TRY(zk_gemv_fused_bf16(xa, L->wgu, L->gu, B, 2 * F, d, d, d, 2 * F, nullptr, 0, 1, L->ln2_w, L->eps, stream));
+  return zk_gemv_fused_bf16(L->gu, L->wdown, out, B, d, F, 2 * F, F, d, add_residual ? xa : nullptr, d, 2, nullptr, 0.f,
+                            stream);
 }

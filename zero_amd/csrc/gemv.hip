@@ -6,42 +6,106 @@
 // CUs.  Four output rows per 256-thread block; the four waves split K in 512-element chunks (a lane
 // owns 8 consecutive k: one 16-byte load per weight row and chunk, 16 independent loads in flight per
 // lane at K = 8192), the lane's x values stay in registers, partial sums are reduced across the wave
-// with DPP adds and across the waves through LDS.  fp32 accumulate, bf16 in/out.
+// with DPP adds and across the waves through LDS.  fp32 accumulate, bf16 in/out.  The x operand can
+// be produced on the fly (RMSNorm of the hidden row, SwiGLU of the gate|up row): two fewer launches
+// per decoder-layer half.
 #include "common.h"
 #include "../../include/zero_hip.h"
 
 namespace {
 
-constexpr int R = 4;   // output rows (weight rows) per block
+constexpr int R = 4;      // output rows (weight rows) per block
+constexpr int NC = 4;     // k-chunks (8 elements) per thread and group: one group covers K = 8192
 
-template <int M>
+// XMODE: what the x operand is.  0 = x as stored; 1 = RMSNorm of x (tf:llama:62-67: w * bf16(x * rstd),
+// rounded to bf16 like the separate kernel's output; the block's 256 threads partition K exactly like
+// rmsnorm_fwd_block_kernel, so rstd is bit-identical); 2 = SwiGLU of the packed gate|up row
+// (x[k] = bf16(bf16(silu(g[k])) * u[k]), g = xin[k], u = xin[K + k]; tf:llama:175).
+// The weight loads of the first group are issued BEFORE the row statistics, so the two HBM/L2 round
+// trips overlap (with them after the reduction's barrier the fused kernel was slower than two launches).
+template <int M, int XMODE>
 __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* x, const bf16_t* W, bf16_t* y, const bf16_t* res,
-                                                   int N, int K, int ldx, int ldw, int ldy, int ldr) {
+                                                   const bf16_t* ln_w, float eps, int N, int K, int ldx, int ldw,
+                                                   int ldy, int ldr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * R;
+  const int k0 = wave * 512 + lane * 8;
+  __shared__ float red[4][M * R];
+  const u32x4 zero = {0u, 0u, 0u, 0u};
   float acc[M][R];
 #pragma unroll
   for (int m = 0; m < M; ++m)
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
-  const u32x4 zero = {0u, 0u, 0u, 0u};
-#pragma unroll 4
-  for (int k = wave * 512 + lane * 8; k < K; k += 2048) {
-    u32x4 wv[R], xv[M];
+  u32x4 wv[NC][R];
+  auto load_w = [&](int kb) {
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-      wv[r] = n0 + r < N ? *reinterpret_cast<const u32x4*>(W + (size_t)(n0 + r) * ldw + k) : zero;
-#pragma unroll
-    for (int m = 0; m < M; ++m) xv[m] = *reinterpret_cast<const u32x4*>(x + (size_t)m * ldx + k);
-#pragma unroll
-    for (int m = 0; m < M; ++m)
+    for (int c = 0; c < NC; ++c) {
+      const int k = kb + k0 + 2048 * c;
 #pragma unroll
       for (int r = 0; r < R; ++r)
+        wv[c][r] = (k < K && n0 + r < N) ? *reinterpret_cast<const u32x4*>(W + (size_t)(n0 + r) * ldw + k) : zero;
+    }
+  };
+  load_w(0);
+  float rstd[M];
+  if (XMODE == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          acc[m][r] += lo_bf(xv[m][e]) * lo_bf(wv[r][e]) + hi_bf(xv[m][e]) * hi_bf(wv[r][e]);
+    for (int m = 0; m < M; ++m) {
+      float ss = 0.f;
+      for (int k = k0; k < K; k += 2048) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + (size_t)m * ldx + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = lo_bf(v[e]), b = hi_bf(v[e]);
+          ss += a * a;
+          ss += b * b;
+        }
+      }
+      ss = wave_sum(ss);
+      if (lane == 0) red[wave][m] = ss;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < M; ++m) rstd[m] = rsqrtf((red[0][m] + red[1][m] + red[2][m] + red[3][m]) / (float)K + eps);
+    __syncthreads();     // red is reused below
   }
-  __shared__ float red[4][M * R];
+  for (int kb = 0;;) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int k = kb + k0 + 2048 * c;
+      if (k < K) {
+        u32x4 lw = zero;
+        if (XMODE == 1) lw = *reinterpret_cast<const u32x4*>(ln_w + k);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          u32x4 xv = *reinterpret_cast<const u32x4*>(x + (size_t)m * ldx + k);
+          if (XMODE == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              xv[e] = pack2bf(lo_bf(lw[e]) * bf2f(f2bf(lo_bf(xv[e]) * rstd[m])),
+                              hi_bf(lw[e]) * bf2f(f2bf(hi_bf(xv[e]) * rstd[m])));
+          } else if (XMODE == 2) {
+            const u32x4 uv = *reinterpret_cast<const u32x4*>(x + (size_t)m * ldx + K + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float g0 = lo_bf(xv[e]), g1 = hi_bf(xv[e]);
+              const float s0 = bf2f(f2bf(g0 / (1.0f + __expf(-g0)))), s1 = bf2f(f2bf(g1 / (1.0f + __expf(-g1))));
+              xv[e] = pack2bf(s0 * lo_bf(uv[e]), s1 * hi_bf(uv[e]));
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[m][r] += lo_bf(xv[e]) * lo_bf(wv[c][r][e]) + hi_bf(xv[e]) * hi_bf(wv[c][r][e]);
+        }
+      }
+    }
+    kb += 2048 * NC;
+    if (kb >= K) break;
+    load_w(kb);
+  }
 #pragma unroll
   for (int m = 0; m < M; ++m)
 #pragma unroll
@@ -61,16 +125,12 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* x, const bf16_t
   }
 }
 
-}  // namespace
-
-extern "C" int zk_gemv_bf16(const void* x, const void* W, void* y, int64_t M, int64_t N, int64_t K, int64_t ldx,
-                            int64_t ldw, int64_t ldy, const void* residual, int64_t ldr, hipStream_t stream) {
-  if (!x || !W || !y || M <= 0 || M > 4 || N <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldw & 7)) return ZK_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) & 15) return ZK_EINVAL;
-  if (N > 0x7FFFFFF0LL || K > 0x7FFFFFF0LL) return ZK_EINVAL;
+template <int XMODE>
+int launch_gemv(const void* x, const void* W, void* y, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
+                int64_t ldy, const void* residual, int64_t ldr, const void* ln_w, float eps, hipStream_t stream) {
   dim3 grid((unsigned)((N + R - 1) / R)), block(256);
-#define CALL(M_) hipLaunchKernelGGL((gemv_kernel<M_>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)W, \
-    (bf16_t*)y, (const bf16_t*)residual, (int)N, (int)K, (int)ldx, (int)ldw, (int)ldy, (int)ldr)
+#define CALL(M_) hipLaunchKernelGGL((gemv_kernel<M_, XMODE>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)W, \
+    (bf16_t*)y, (const bf16_t*)residual, (const bf16_t*)ln_w, eps, (int)N, (int)K, (int)ldx, (int)ldw, (int)ldy, (int)ldr)
   switch (M) {
     case 1: CALL(1); break;
     case 2: CALL(2); break;
@@ -80,4 +140,23 @@ extern "C" int zk_gemv_bf16(const void* x, const void* W, void* y, int64_t M, in
 #undef CALL
   ZK_CHECK_LAUNCH();
   return ZK_OK;
+}
+
+}  // namespace
+
+extern "C" int zk_gemv_fused_bf16(const void* x, const void* W, void* y, int64_t M, int64_t N, int64_t K, int64_t ldx,
+                                  int64_t ldw, int64_t ldy, const void* residual, int64_t ldr, int xmode,
+                                  const void* ln_w, float eps, hipStream_t stream) {
+  if (!x || !W || !y || M <= 0 || M > 4 || N <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldw & 7))
+    return ZK_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) & 15) return ZK_EINVAL;
+  if (N > 0x7FFFFFF0LL || xmode < 0 || xmode > 2 || (xmode == 1 && !ln_w) || (xmode == 2 && ldx < 2 * K)) return ZK_EINVAL;
+  if (xmode == 1) return launch_gemv<1>(x, W, y, M, N, K, ldx, ldw, ldy, residual, ldr, ln_w, eps, stream);
+  if (xmode == 2) return launch_gemv<2>(x, W, y, M, N, K, ldx, ldw, ldy, residual, ldr, nullptr, 0.f, stream);
+  return launch_gemv<0>(x, W, y, M, N, K, ldx, ldw, ldy, residual, ldr, nullptr, 0.f, stream);
+}
+
+extern "C" int zk_gemv_bf16(const void* x, const void* W, void* y, int64_t M, int64_t N, int64_t K, int64_t ldx,
+                            int64_t ldw, int64_t ldy, const void* residual, int64_t ldr, hipStream_t stream) {
+  return zk_gemv_fused_bf16(x, W, y, M, N, K, ldx, ldw, ldy, residual, ldr, 0, nullptr, 0.f, stream);
 }

@@ -111,6 +111,22 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
     return out
 
 
+def gemv_fused(x, w, *, xmode: int, ln_w=None, eps: float = 0.0, residual=None, out=None):
+    """Decode-time product with the x operand made on the fly: xmode 1 = RMSNorm(x; ln_w, eps),
+    xmode 2 = SwiGLU of the packed gate|up rows x [M, 2K].  M <= 4."""
+    _chk2d(x, "x"); _chk2d(w, "w")
+    M = x.shape[0]
+    N, K = w.shape
+    if (xmode == 2 and x.shape[1] != 2 * K) or (xmode != 2 and x.shape[1] != K):
+        raise ValueError("gemv_fused: operand widths")
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=x.device)
+    ldr = _ld(residual) if residual is not None else 0
+    check(lib.zk_gemv_fused_bf16(_p(x), _p(w), _p(out), M, N, K, _ld(x), _ld(w), _ld(out), _p(residual), ldr, xmode,
+                                 _p(ln_w), float(eps), _stream()), "zk_gemv_fused_bf16")
+    return out
+
+
 def interleave_gate_up(gate_w: torch.Tensor, up_w: torch.Tensor) -> torch.Tensor:
     """[2F, in] weight whose row blocks of 64 are [32 gate rows | the matching 32 up rows]: the layout
     the fused SwiGLU epilogues expect (include/zero_hip.h, ZK_EPI_SWIGLU).  One-time preparation."""
