@@ -256,6 +256,34 @@ int zk_f32_to_bf16(const float* src, void* dst, int64_t n, float scale, int accu
 int zk_f32_to_bf16_multi(const float* const* src, void* const* dst, const int64_t* n,
                          const int* accumulate, int count, float scale, hipStream_t stream);
 
+/* ---- image data path -------------------------------------------------
+ * What ref:loader.py:171-195 does per sample with PIL + CLIPImageProcessor (PIL backend):
+ * expand2square (ref:loader.py:609-620), Image.resize (bicubic, antialiased; ref:loader.py:677,759
+ * and tf:image_transforms.py resize), centre crop, anyres canvas + tiling (ref:loader.py:731-789),
+ * rescale + normalize (tf:image_transforms.py:118-122, normalize).  u8 RGB images are [h][w][3]
+ * with a row stride in BYTES.  The resampler is Pillow's 8-bit one (Pillow 12.2.0
+ * src/libImaging/Resample.c): `bounds` = (first source index, tap count) per output index, `kk` =
+ * ksize int32 coefficients per output index in 22-bit fixed point, both made by the host exactly as
+ * precompute_coeffs / normalize_coeffs_8bpc make them.  Results are bit-identical to PIL.
+ *   resample_rows : horizontal pass over `rows` rows of the VIRTUAL image (src pasted at
+ *                   (paste_x, paste_y) on a canvas of colour bg_rgb = r | g<<8 | b<<16; negative
+ *                   paste = crop), out [rows][out_w][3] packed.
+ *   resample_cols : vertical pass over byte columns, in [in_h][row_bytes] -> out [out_h][row_bytes].
+ *   patches_normalize : out [n_patches][3][patch][patch] (fp32, or bf16 when out_bf16) where patch p
+ *                   is canvas rows (p / grid_x) * patch.., columns (p % grid_x) * patch.. of the
+ *                   virtual image, mapped through lut[3][256] (the host's rescale+normalize of every
+ *                   byte value per channel).
+ */
+int zk_u8_resample_rows(const uint8_t* src, int64_t src_h, int64_t src_w, int64_t src_ld, int64_t rows,
+                        int64_t paste_x, int64_t paste_y, uint32_t bg_rgb, const int32_t* bounds,
+                        const int32_t* kk, int ksize, int64_t out_w, uint8_t* out, hipStream_t stream);
+int zk_u8_resample_cols(const uint8_t* in, int64_t in_h, int64_t row_bytes, const int32_t* bounds,
+                        const int32_t* kk, int ksize, int64_t out_h, uint8_t* out, hipStream_t stream);
+int zk_u8_patches_normalize(const uint8_t* img, int64_t img_h, int64_t img_w, int64_t img_ld,
+                            int64_t paste_x, int64_t paste_y, uint32_t bg_rgb, int64_t grid_x,
+                            int64_t patch, int64_t n_patches, const float* lut, void* out, int out_bf16,
+                            hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

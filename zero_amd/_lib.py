@@ -5,7 +5,7 @@ never silently route around the HIP kernels.
 """
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int64, c_void_p
+from ctypes import c_float, c_int, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzero_hip.so")
@@ -50,6 +50,9 @@ SIGNATURES = {
     "zk_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P, _F, _P],
     "zk_f32_to_bf16": [_P, _P, _L, _F, _I, _P],
     "zk_f32_to_bf16_multi": [_P, _P, _P, _P, _I, _F, _P],
+    "zk_u8_resample_rows": [_P, _L, _L, _L, _L, _L, _L, c_uint32, _P, _P, _I, _L, _P, _P],
+    "zk_u8_resample_cols": [_P, _L, _L, _P, _P, _I, _L, _P, _P],
+    "zk_u8_patches_normalize": [_P, _L, _L, _L, _L, _L, c_uint32, _L, _L, _L, _P, _P, _I, _P],
 }
 
 for _name, _args in SIGNATURES.items():

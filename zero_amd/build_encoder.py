@@ -10,18 +10,8 @@ from __future__ import annotations
 
 import torch
 
+from .loader import CLIPImageProcessorHip
 from .models.clip import CLIPVisionConfig, CLIPVisionModel
-
-
-class ImageProcessorStub:
-    """Carries only what the reference reads from CLIPImageProcessor on this path
-    (ref:build_encoder.py:27): ``size["shortest_edge"]`` and the CLIP mean/std constants."""
-
-    def __init__(self, size: int):
-        self.size = {"shortest_edge": size}
-        self.crop_size = {"height": size, "width": size}
-        self.image_mean = [0.48145466, 0.4578275, 0.40821073]
-        self.image_std = [0.26862954, 0.26130258, 0.27577711]
 
 
 def load_clip(cfg: object, model_name: str = "openai/clip-vit-large-patch14-336"):
@@ -31,6 +21,8 @@ def load_clip(cfg: object, model_name: str = "openai/clip-vit-large-patch14-336"
     model = CLIPVisionModel(ccfg, device=device)
     if getattr(cfg, "ptdtype", torch.bfloat16) != torch.bfloat16:
         raise ValueError("zero_amd kernels compute in bf16 (ref:configs/zero/train_llama.py:80)")
-    processor = ImageProcessorStub(ccfg.image_size)
+    # the reference loads CLIPImageProcessor.from_pretrained (ref:build_encoder.py:24); here the same pipeline
+    # with the public CLIP mean/std constants, running on the device (zero_amd/loader.py)
+    processor = CLIPImageProcessorHip(ccfg.image_size, device=device)
     image_input_size = processor.size["shortest_edge"]
     return model, processor, image_input_size
