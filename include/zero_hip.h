@@ -131,12 +131,27 @@ int zk_attn_decode(const void* q, const void* k_cache, const void* v_cache, void
                    int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t batch_stride_k,
                    int64_t batch_stride_v, int64_t max_len, float scale, hipStream_t stream);
 
+/* The same with the new token's RoPE and cache append folded in and the cache split over workgroups
+ * (flash-decoding): replaces zk_rope + the k/v append + zk_attn_decode of one decoding step by a
+ * partial pass (one workgroup per 64 cached keys, kv head and sequence; the q heads of a GQA group share
+ * the K / V rows) and a merge pass.  qkv [B][ldqkv]: the new token's packed q|k|v BEFORE RoPE
+ * (tf:llama:254-259), left untouched; cos_row / sin_row: the fp32 table rows of position `pos`
+ * ([head_dim / 2]); caches [B][cache_rows][Hkv*hd]: row `pos` is written (rotated k, v), rows 0..pos are
+ * attended; every sequence is at the same position.  ws: caller-owned fp32 workspace of at least
+ * B * Hq * (pos / 64 + 1) * (head_dim + 2) floats.  Hq / Hkv <= 16, head_dim 64 or 128. */
+int zk_attn_decode_fused(const void* qkv, const float* cos_row, const float* sin_row, void* k_cache,
+                         void* v_cache, void* out, float* ws, int64_t ws_floats, int64_t B, int64_t Hq,
+                         int64_t Hkv, int64_t head_dim, int64_t ldqkv, int64_t ldo, int64_t cache_rows,
+                         int64_t pos, float scale, hipStream_t stream);
+
 /* One Llama decoder layer on a single-token decoding step, enqueued natively in two halves so a
  * tensor-parallel host can all-reduce the partial sums between them (tf:llama:295-324 with a KV cache;
  * ref:inference/vlm_infer.py:259-270).  Head counts and F are the LOCAL (sharded) ones; wqkv / wgu are
  * the packed q|k|v and gate|up weights ([rows][d], k contiguous); the caches are
  * [B][cache_rows][nkv*hd]; lens (device int32 [B]) must hold pos + 1; h / qkv / ao / gu / hm are
- * caller-owned scratch rows ([B][d], [B][(nh+2nkv)hd], [B][nh*hd], [B][2F], [B][F]).
+ * caller-owned scratch rows ([B][d], [B][(nh+2nkv)hd], [B][nh*hd], [B][2F], [B][F]); attn_ws
+ * (optional, attn_ws_floats fp32 values, sized as zk_attn_decode_fused asks for cache_rows keys) switches
+ * the attention to the split-cache kernels, otherwise zk_rope + append + zk_attn_decode run.
  *   attn: out = (add_residual ? x : 0) + o_proj(attention(rope(qkv(rmsnorm(x)))))   and appends k, v
  *   mlp : out = (add_residual ? xa : 0) + down(silu(gate(rmsnorm(xa))) * up(rmsnorm(xa)))
  * B <= 4.  Allocates nothing, never synchronises. */
@@ -148,6 +163,8 @@ typedef struct {
   void *k_cache, *v_cache;
   const int* lens;
   void *h, *qkv, *ao, *gu, *hm;
+  float* attn_ws;
+  int64_t attn_ws_floats;
 } zk_decode_layer_t;
 int zk_llama_decode_attn(const zk_decode_layer_t* L, const void* x, void* out, int add_residual,
                          hipStream_t stream);

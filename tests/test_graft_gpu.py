@@ -52,12 +52,59 @@ def test_attn_decode_kernel(B, Hq, Hkv, hd, rows, lens):
         assert maxrel(out[b], ref) < 8e-3, (b, L)
 
 
-@pytest.mark.parametrize("native", [True, False], ids=["native-layer-driver", "python-launches"])
+@pytest.mark.parametrize("B,Hq,Hkv,hd,rows,pos", [(1, 8, 1, 128, 1100, 1027), (2, 24, 8, 128, 300, 63), (2, 24, 8, 128, 300, 64),
+                                                  (3, 6, 6, 64, 70, 0), (4, 32, 2, 64, 200, 199), (1, 64, 8, 128, 900, 800)])
+def test_attn_decode_fused_kernel(B, Hq, Hkv, hd, rows, pos):
+    """RoPE + cache append + split-cache attention + merge (zk_attn_decode_fused) against fp32 torch, and
+    against the separate kernels it replaces (zk_rope, append, zk_attn_decode)."""
+    from zero_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(11)
+    W = (Hq + 2 * Hkv) * hd
+    qkv = torch.randn(B, W, generator=g).to(torch.bfloat16).to(DEV)
+    kc = torch.randn(B, rows, Hkv * hd, generator=g).to(torch.bfloat16).to(DEV)
+    vc = torch.randn(B, rows, Hkv * hd, generator=g).to(torch.bfloat16).to(DEV)
+    ang = torch.rand(rows, hd // 2, generator=g) * 6.28
+    cos_t, sin_t = ang.cos().to(DEV).contiguous(), ang.sin().to(DEV).contiguous()
+    kc0, vc0, qkv0 = kc.clone(), vc.clone(), qkv.clone()
+    out = ops.attn_decode_fused(qkv, cos_t, sin_t, kc, vc, pos, Hq, Hkv, hd, hd ** -0.5)
+    assert torch.equal(qkv, qkv0)
+    # the separate kernels
+    q2 = qkv0.clone()
+    ops.rope_(q2, cos_t[pos:pos + 1], sin_t[pos:pos + 1], 1, Hq + Hkv, hd)
+    k_new, v_new = q2[:, Hq * hd:(Hq + Hkv) * hd], q2[:, (Hq + Hkv) * hd:]
+    kc2, vc2 = kc0.clone(), vc0.clone()
+    kc2[:, pos], vc2[:, pos] = k_new, v_new
+    ln = torch.full((B,), pos + 1, dtype=torch.int32, device=DEV)
+    old = ops.attn_decode(q2[:, :Hq * hd], kc2, vc2, ln, pos + 1, Hq, Hkv, hd, hd ** -0.5)
+    # cache: row pos appended (same values up to the RoPE's last-bit rounding), every other row untouched
+    assert torch.equal(vc, vc2)
+    assert maxrel(kc[:, pos], kc2[:, pos]) < 8e-3
+    keep = torch.ones(rows, dtype=torch.bool, device=DEV)
+    keep[pos] = False
+    assert torch.equal(kc[:, keep], kc0[:, keep])
+    assert maxrel(out, old) < 8e-3
+    rep = Hq // Hkv
+    for b in range(B):
+        L = pos + 1
+        qf = q2[b, :Hq * hd].float().view(Hq, hd)
+        kf = kc2[b, :L].float().view(L, Hkv, hd).repeat_interleave(rep, dim=1)
+        vf = vc2[b, :L].float().view(L, Hkv, hd).repeat_interleave(rep, dim=1)
+        p = torch.softmax(torch.einsum("hd,lhd->hl", qf, kf) * hd ** -0.5, dim=-1)
+        ref = torch.einsum("hl,lhd->hd", p, vf).reshape(-1)
+        assert maxrel(out[b], ref) < 8e-3, (b, L)
+    with pytest.raises(ValueError):
+        ops.attn_decode_fused(qkv, cos_t, sin_t, kc, vc, pos, Hq, Hkv, hd, hd ** -0.5, ws=torch.empty(8, device=DEV))
+
+
+@pytest.mark.parametrize("native", [True, False, "unsplit"], ids=["native-layer-driver", "python-launches", "native-unsplit-attention"])
 def test_kv_cache_decode_matches_full_recompute(native, monkeypatch):
     """Prefill + 5 cached single-token steps on unit-scale random embeddings == the causal forward over
     the whole grown sequence (HIP training path, and the fp32 oracle): catches cache / position bugs."""
     from zero_amd.inference import decode
     from zero_amd.inference.decode import KVCache, forward_cached
+    if native == "unsplit":
+        native = True
+        monkeypatch.setattr(decode, "USE_SPLIT_ATTENTION", False)
     monkeypatch.setattr(decode, "USE_NATIVE_DECODE", native)
     spec = GOLDEN_CONFIGS["graft"]
     params, cfg, model = _model(spec)

@@ -30,6 +30,7 @@ SIGNATURES = {
     "zk_attn_fwd": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "zk_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "zk_attn_decode": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P],
+    "zk_attn_decode_fused": [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P],
     "zk_llama_decode_attn": [_P, _P, _P, _I, _P],
     "zk_llama_decode_mlp": [_P, _P, _P, _I, _P],
     "zk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _L, _F, _P],
@@ -69,7 +70,8 @@ class DecodeLayer(ctypes.Structure):
     """zk_decode_layer_t of include/zero_hip.h."""
     _fields_ = ([(n, c_int64) for n in ("B", "d", "nh", "nkv", "hd", "F", "cache_rows", "pos")] + [("eps", c_float)] +
                 [(n, c_void_p) for n in ("ln1_w", "wqkv", "wo", "ln2_w", "wgu", "wdown", "cos_t", "sin_t", "k_cache",
-                                         "v_cache", "lens", "h", "qkv", "ao", "gu", "hm")])
+                                         "v_cache", "lens", "h", "qkv", "ao", "gu", "hm", "attn_ws")] +
+                [("attn_ws_floats", c_int64)])
 
 
 class ZeroHipError(RuntimeError):

@@ -656,7 +656,229 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* q, const
   }
 }
 
+// =========================================================================================
+// The same single-query attention, split over the cache (flash-decoding) and with the new token's
+// RoPE + cache append folded in: one block per (64-key chunk, kv head, sequence) instead of one per
+// query head, so a tensor-parallel shard with one kv head (70B / 8) spreads over len/64 CUs instead of
+// 8, and the q heads of a GQA group share every K / V row they read.  Partials (un-normalised output,
+// chunk max, chunk sum) go to the caller's fp32 workspace; a second small kernel merges them.
+//   qkv: the new token's packed q|k|v rows BEFORE RoPE (tf:llama:254-259); the block of the last
+//   chunk rotates k, appends k / v to the caches (row `pos`) and then reads them like any other row.
+// =========================================================================================
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* qkv, int ldqkv, const float* cosr,
+                                                                const float* sinr, bf16_t* kc, bf16_t* vc,
+                                                                long long bstride, int kvw, float* ws, int Hq, int Hkv,
+                                                                int pos, int nchunks, float scale) {
+  constexpr int CK = 64, HALF = HD / 2, LPR = HD / 8, KS = 64 / LPR, MAXG = 16;
+  __shared__ float qs[MAXG][HD];
+  __shared__ float ps[MAXG][CK];
+  __shared__ __attribute__((aligned(16))) bf16_t knew[HD];
+  __shared__ __attribute__((aligned(16))) bf16_t vnew[HD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+  const int G = Hq / Hkv;
+  const bf16_t* row = qkv + (size_t)b * ldqkv;
+  bf16_t* kb = kc + (size_t)b * bstride + (size_t)kvh * HD;
+  bf16_t* vb = vc + (size_t)b * bstride + (size_t)kvh * HD;
+  const int j0 = chunk * CK;
+  const bool last = chunk == nchunks - 1;
+  // Every K / V row this thread will need is requested before anything else (the loads do not depend on
+  // q or on the scores): one memory round trip for the whole block instead of one per phase.  Row `pos`
+  // is not in the cache yet: the last chunk's block patches it in from the new token's k / v below.
+  const int jk = j0 + lane;                       // this lane's key (scores)
+  const bool valid = jk <= pos;
+  const int dch = lane % LPR, sl = lane / LPR;    // this lane's V columns / key slice (output)
+  u32x4 kr[HD / 8], vr[CK / KS];
+  {
+    const bf16_t* kp = kb + (size_t)(valid && jk != pos ? jk : 0) * kvw;
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) kr[c] = *reinterpret_cast<const u32x4*>(kp + c * 8);
+#pragma unroll
+    for (int i = 0; i < CK / KS; ++i) {
+      const int j = j0 + sl + KS * i;
+      const u32x4 t = *reinterpret_cast<const u32x4*>(vb + (size_t)(j < pos ? j : 0) * kvw + dch * 8);
+      vr[i] = j < pos ? t : u32x4{0u, 0u, 0u, 0u};      // never multiply a stale row (0 x NaN)
+    }
+  }
+  // q of the group: rotate, round to bf16 (what the separate RoPE kernel stores), scale
+  for (int i = tid; i < G * HALF; i += 256) {
+    const int h = i / HALF, j = i % HALF;
+    const bf16_t* qh = row + (size_t)(kvh * G + h) * HD;
+    const float a = bf2f(qh[j]), c = bf2f(qh[j + HALF]), cs = cosr[j], sn = sinr[j];
+    qs[h][j] = bf2f(f2bf(a * cs - c * sn)) * scale;
+    qs[h][j + HALF] = bf2f(f2bf(c * cs + a * sn)) * scale;
+  }
+  if (last) {      // the chunk that holds row `pos`: rotate k, append k / v, keep them for this block
+    const bf16_t* kn = row + (size_t)Hq * HD + (size_t)kvh * HD;
+    const bf16_t* vn = row + (size_t)(Hq + Hkv) * HD + (size_t)kvh * HD;
+    if (tid < HALF) {
+      const float a = bf2f(kn[tid]), c = bf2f(kn[tid + HALF]), cs = cosr[tid], sn = sinr[tid];
+      const bf16_t k1 = f2bf(a * cs - c * sn), k2 = f2bf(c * cs + a * sn);
+      kb[(size_t)pos * kvw + tid] = k1;
+      kb[(size_t)pos * kvw + tid + HALF] = k2;
+      knew[tid] = k1;
+      knew[tid + HALF] = k2;
+    } else if (tid >= 128 && tid < 128 + HD) {
+      const bf16_t v = vn[tid - 128];
+      vb[(size_t)pos * kvw + (tid - 128)] = v;
+      vnew[tid - 128] = v;
+    }
+  }
+  __syncthreads();
+  if (last) {
+    if (jk == pos) {
+#pragma unroll
+      for (int c = 0; c < HD / 8; ++c) kr[c] = *reinterpret_cast<const u32x4*>(&knew[c * 8]);
+    }
+#pragma unroll
+    for (int i = 0; i < CK / KS; ++i)
+      if (j0 + sl + KS * i == pos) vr[i] = *reinterpret_cast<const u32x4*>(&vnew[dch * 8]);
+  }
+  float* wsb = ws + ((size_t)(b * Hq + kvh * G) * nchunks + chunk) * (HD + 2);
+  const size_t hstride = (size_t)nchunks * (HD + 2);
+  for (int h = wave; h < G; h += 4) {
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        dot += lo_bf(kr[c][e]) * qs[h][c * 8 + 2 * e] + hi_bf(kr[c][e]) * qs[h][c * 8 + 2 * e + 1];
+    }
+    const float sc = valid ? dot : -3.0e38f;
+    const float m = wave_max(sc);
+    const float p = valid ? __expf(sc - m) : 0.f;
+    const float l = wave_sum(p);
+    ps[h][lane] = p;                 // 0 for keys beyond pos: their (clamped) V rows add nothing
+    if (lane == 0) {
+      wsb[h * hstride + HD] = m;
+      wsb[h * hstride + HD + 1] = l;
+    }
+  }
+  __syncthreads();
+  {
+    float acc[4][8];
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[hh][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < CK / KS; ++i) {
+      const int key = sl + KS * i;
+#pragma unroll
+      for (int hh = 0; hh < 4; ++hh) {
+        const int h = wave + 4 * hh;
+        if (h < G) {
+          const float p = ps[h][key];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[hh][2 * e] += p * lo_bf(vr[i][e]);
+            acc[hh][2 * e + 1] += p * hi_bf(vr[i][e]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {
+      const int h = wave + 4 * hh;
+      if (h < G) {      // wave-uniform
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+          for (int o = LPR; o < 64; o <<= 1) acc[hh][e] += __shfl_xor(acc[hh][e], o, 64);
+        }
+        if (lane < LPR) {
+          float* o = wsb + h * hstride + dch * 8;
+          *reinterpret_cast<f32x4*>(o) = f32x4{acc[hh][0], acc[hh][1], acc[hh][2], acc[hh][3]};
+          *reinterpret_cast<f32x4*>(o + 4) = f32x4{acc[hh][4], acc[hh][5], acc[hh][6], acc[hh][7]};
+        }
+      }
+    }
+  }
+}
+
+// out[b][h][:] = sum_c O_c e^(m_c - M) / sum_c l_c e^(m_c - M): one block of HD threads per (b, h)
+template <int HD>
+__global__ __launch_bounds__(HD) void attn_decode_merge_kernel(const float* ws, bf16_t* out, int ldo, int Hq,
+                                                               int nchunks) {
+  __shared__ float wgt[256];       // e^(m_c - M) of up to 256 chunks per round
+  __shared__ float red[HD / 64 * 2];
+  const int b = blockIdx.x / Hq, h = blockIdx.x % Hq, d = threadIdx.x, lane = d & 63, wave = d >> 6;
+  const float* w = ws + (size_t)blockIdx.x * nchunks * (HD + 2);
+  // chunk maxima: one load per thread and round (independent loads), block max through LDS
+  float M = -3.0e38f;
+  for (int c = d; c < nchunks; c += HD) M = fmaxf(M, w[(size_t)c * (HD + 2) + HD]);
+  M = wave_max(M);
+  if (lane == 0) red[wave] = M;
+  __syncthreads();
+  M = red[0];
+#pragma unroll
+  for (int i = 1; i < HD / 64; ++i) M = fmaxf(M, red[i]);
+  __syncthreads();
+  float L = 0.f, o = 0.f;
+  for (int c0 = 0; c0 < nchunks; c0 += 256) {
+    const int nc = min(256, nchunks - c0);
+    for (int c = d; c < nc; c += HD) {
+      const float f = __expf(w[(size_t)(c0 + c) * (HD + 2) + HD] - M);
+      wgt[c] = f;
+      L += w[(size_t)(c0 + c) * (HD + 2) + HD + 1] * f;
+    }
+    __syncthreads();
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    int c = 0;
+    for (; c + 4 <= nc; c += 4) {      // four independent loads in flight
+      o0 += w[(size_t)(c0 + c) * (HD + 2) + d] * wgt[c];
+      o1 += w[(size_t)(c0 + c + 1) * (HD + 2) + d] * wgt[c + 1];
+      o2 += w[(size_t)(c0 + c + 2) * (HD + 2) + d] * wgt[c + 2];
+      o3 += w[(size_t)(c0 + c + 3) * (HD + 2) + d] * wgt[c + 3];
+    }
+    for (; c < nc; ++c) o0 += w[(size_t)(c0 + c) * (HD + 2) + d] * wgt[c];
+    o += (o0 + o1) + (o2 + o3);
+    __syncthreads();
+  }
+  L = wave_sum(L);
+  if (lane == 0) red[HD / 64 + wave] = L;
+  __syncthreads();
+  L = red[HD / 64];
+#pragma unroll
+  for (int i = 1; i < HD / 64; ++i) L += red[HD / 64 + i];
+  out[(size_t)b * ldo + (size_t)h * HD + d] = f2bf(o / L);
+}
+
 }  // namespace
+
+extern "C" int zk_attn_decode_fused(const void* qkv, const float* cos_row, const float* sin_row, void* k_cache,
+                                    void* v_cache, void* out, float* ws, int64_t ws_floats, int64_t B, int64_t Hq,
+                                    int64_t Hkv, int64_t head_dim, int64_t ldqkv, int64_t ldo, int64_t cache_rows,
+                                    int64_t pos, float scale, hipStream_t stream) {
+  if (!qkv || !cos_row || !sin_row || !k_cache || !v_cache || !out || !ws) return ZK_EINVAL;
+  if (B <= 0 || B > 65535 || Hq <= 0 || Hkv <= 0 || Hkv > 65535 || Hq % Hkv || Hq / Hkv > 16) return ZK_EINVAL;
+  if ((head_dim != 64 && head_dim != 128) || pos < 0 || pos >= cache_rows || (ldqkv & 7)) return ZK_EINVAL;
+  if (ldqkv < (Hq + 2 * Hkv) * head_dim || ldo < Hq * head_dim) return ZK_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(k_cache) | reinterpret_cast<uintptr_t>(v_cache) | reinterpret_cast<uintptr_t>(qkv) |
+       reinterpret_cast<uintptr_t>(ws)) & 15)
+    return ZK_EINVAL;
+  const int64_t nchunks = pos / 64 + 1;
+  if (nchunks > 0x7FFFFFFF || ws_floats < B * Hq * nchunks * (head_dim + 2)) return ZK_EINVAL;
+  if (cache_rows * Hkv * head_dim >= 0x7FFFFFFFFFFFLL) return ZK_EINVAL;
+  const int kvw = (int)(Hkv * head_dim);
+  dim3 grid((unsigned)nchunks, (unsigned)Hkv, (unsigned)B);
+  if (head_dim == 128) {
+    hipLaunchKernelGGL((attn_decode_split_kernel<128>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, (int)ldqkv,
+                       cos_row, sin_row, (bf16_t*)k_cache, (bf16_t*)v_cache, (long long)(cache_rows * kvw), kvw, ws,
+                       (int)Hq, (int)Hkv, (int)pos, (int)nchunks, scale);
+    hipLaunchKernelGGL((attn_decode_merge_kernel<128>), dim3((unsigned)(B * Hq)), dim3(128), 0, stream,
+                       (const float*)ws, (bf16_t*)out, (int)ldo, (int)Hq, (int)nchunks);
+  } else {
+    hipLaunchKernelGGL((attn_decode_split_kernel<64>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, (int)ldqkv,
+                       cos_row, sin_row, (bf16_t*)k_cache, (bf16_t*)v_cache, (long long)(cache_rows * kvw), kvw, ws,
+                       (int)Hq, (int)Hkv, (int)pos, (int)nchunks, scale);
+    hipLaunchKernelGGL((attn_decode_merge_kernel<64>), dim3((unsigned)(B * Hq)), dim3(64), 0, stream,
+                       (const float*)ws, (bf16_t*)out, (int)ldo, (int)Hq, (int)nchunks);
+  }
+  ZK_CHECK_LAUNCH();
+  return ZK_OK;
+}
 
 extern "C" int zk_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out, const int* lens,
                               int64_t B, int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk,

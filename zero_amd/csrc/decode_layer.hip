@@ -42,6 +42,13 @@ extern "C" int zk_llama_decode_attn(const zk_decode_layer_t* L, const void* x, v
   const int64_t B = L->B, d = L->d, hd = L->hd, qw = L->nh * hd, kvw = L->nkv * hd, W = qw + 2 * kvw;
   // RMSNorm fused into the q|k|v product (d > 16384 would need the separate kernel: not a Llama shape)
   ZK_TRY(zk_gemv_fused_bf16(x, L->wqkv, L->qkv, B, W, d, d, d, W, nullptr, 0, 1, L->ln1_w, L->eps, stream));
+  if (L->attn_ws && L->nh / L->nkv <= 16 && L->attn_ws_floats >= B * L->nh * (L->pos / 64 + 1) * (hd + 2)) {
+    // RoPE + cache append + split-cache attention + merge: two launches
+    ZK_TRY(zk_attn_decode_fused(L->qkv, L->cos_t + L->pos * (hd / 2), L->sin_t + L->pos * (hd / 2), L->k_cache,
+                                L->v_cache, L->ao, L->attn_ws, L->attn_ws_floats, B, L->nh, L->nkv, hd, W, qw,
+                                L->cache_rows, L->pos, 1.0f / sqrtf((float)hd), stream));
+    return zk_gemv_bf16(L->ao, L->wo, out, B, d, qw, qw, qw, d, add_residual ? x : nullptr, d, stream);
+  }
   // every row is position `pos`: a one-row table (S = 1) starting at that position
   ZK_TRY(zk_rope(L->qkv, L->cos_t + L->pos * (hd / 2), L->sin_t + L->pos * (hd / 2), B, 1, L->nh + L->nkv, hd, W, 0,
                  stream));

@@ -125,10 +125,74 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* x, const bf16_t
   }
 }
 
+// Short contractions (K <= 2048: the o-projection of a tensor-parallel shard, K = 1024): with K split over
+// the four waves half of them would idle and a thread would have 4 loads in flight.  Here a WAVE owns
+// RW output rows and its lanes split K, two 512-element chunks per step: 8 weight loads in flight per
+// lane, no cross-wave reduction, 16 rows per block.
+template <int M>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const bf16_t* x, const bf16_t* W, bf16_t* y, const bf16_t* res,
+                                                        int N, int K, int ldx, int ldw, int ldy, int ldr) {
+  constexpr int RW = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 4 + wave) * RW;
+  if (n0 >= N) return;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  float acc[M][RW];
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < RW; ++r) acc[m][r] = 0.f;
+  for (int kb = lane * 8; kb < K; kb += 1024) {
+    u32x4 wv[2][RW], xv[2][M];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int k = kb + 512 * c;
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+        wv[c][r] = (k < K && n0 + r < N) ? *reinterpret_cast<const u32x4*>(W + (size_t)(n0 + r) * ldw + k) : zero;
+#pragma unroll
+      for (int m = 0; m < M; ++m) xv[c][m] = k < K ? *reinterpret_cast<const u32x4*>(x + (size_t)m * ldx + k) : zero;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[m][r] += lo_bf(xv[c][m][e]) * lo_bf(wv[c][r][e]) + hi_bf(xv[c][m][e]) * hi_bf(wv[c][r][e]);
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      float v = wave_sum(acc[m][r]);
+      if (lane == 0 && n0 + r < N) {
+        if (res) v = bf2f(f2bf(v)) + bf2f(res[(size_t)m * ldr + n0 + r]);
+        y[(size_t)m * ldy + n0 + r] = f2bf(v);
+      }
+    }
+}
+
 template <int XMODE>
 int launch_gemv(const void* x, const void* W, void* y, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
                 int64_t ldy, const void* residual, int64_t ldr, const void* ln_w, float eps, hipStream_t stream) {
   dim3 grid((unsigned)((N + R - 1) / R)), block(256);
+  if (XMODE == 0 && K <= 2048) {
+    dim3 g2((unsigned)((N + 15) / 16));
+#define CALLR(M_) hipLaunchKernelGGL((gemv_rows_kernel<M_>), g2, block, 0, stream, (const bf16_t*)x, (const bf16_t*)W, \
+    (bf16_t*)y, (const bf16_t*)residual, (int)N, (int)K, (int)ldx, (int)ldw, (int)ldy, (int)ldr)
+    switch (M) {
+      case 1: CALLR(1); break;
+      case 2: CALLR(2); break;
+      case 3: CALLR(3); break;
+      default: CALLR(4); break;
+    }
+#undef CALLR
+    ZK_CHECK_LAUNCH();
+    return ZK_OK;
+  }
 #define CALL(M_) hipLaunchKernelGGL((gemv_kernel<M_, XMODE>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)W, \
     (bf16_t*)y, (const bf16_t*)residual, (const bf16_t*)ln_w, eps, (int)N, (int)K, (int)ldx, (int)ldw, (int)ldy, (int)ldr)
   switch (M) {

@@ -18,6 +18,7 @@ from .. import ops
 from ..distributed.tensor_parallel import TPContext
 
 BF16 = torch.bfloat16
+USE_SPLIT_ATTENTION = True   # native steps: RoPE + append + split-cache attention (False: zk_rope, append, zk_attn_decode)
 USE_NATIVE_DECODE = True     # single-token steps through the C layer drivers (False: kernel by kernel from Python)
 
 
@@ -109,6 +110,9 @@ class DecodePlan:
         mk = lambda n: torch.empty((B, n), dtype=BF16, device=dev)
         self.scratch = [mk(d), mk((nh + 2 * nkv) * hd), mk(nh * hd), mk(2 * F), mk(F)]
         self.bufs = [mk(d), mk(d), mk(d)]                 # layer input / attention-half output / layer output
+        # fp32 partials of the split-cache attention (shared by all layers: the stream orders them)
+        ws_floats = B * nh * ((cache.max_len + 63) // 64) * (hd + 2)
+        self.attn_ws = torch.empty(ws_floats, dtype=torch.float32, device=dev) if USE_SPLIT_ATTENTION else None
         self.keep = []                                    # views the structs point into
         self.structs = []
         for li, layer in enumerate(layers):
@@ -124,7 +128,9 @@ class DecodePlan:
                              wgu=wgu.data_ptr(), wdown=m.down_proj.weight.data_ptr(), cos_t=cos_t.data_ptr(),
                              sin_t=sin_t.data_ptr(), k_cache=cache.k[li].data_ptr(), v_cache=cache.v[li].data_ptr(),
                              lens=cache.lens.data_ptr(), h=self.scratch[0].data_ptr(), qkv=self.scratch[1].data_ptr(),
-                             ao=self.scratch[2].data_ptr(), gu=self.scratch[3].data_ptr(), hm=self.scratch[4].data_ptr())
+                             ao=self.scratch[2].data_ptr(), gu=self.scratch[3].data_ptr(), hm=self.scratch[4].data_ptr(),
+                             attn_ws=self.attn_ws.data_ptr() if self.attn_ws is not None else None,
+                             attn_ws_floats=ws_floats if self.attn_ws is not None else 0)
             self.structs.append(st)
         self._byref = [ctypes.byref(s_) for s_ in self.structs]
 

@@ -219,6 +219,35 @@ def attn_decode(q, k_cache, v_cache, lens_i32, max_len: int, Hq: int, Hkv: int, 
     return out
 
 
+def attn_decode_fused(qkv, cos_t, sin_t, k_cache, v_cache, pos: int, Hq: int, Hkv: int, hd: int, scale: float,
+                      ws: Optional[torch.Tensor] = None, out=None):
+    """Single-token decoding step of the attention: RoPE of the new q / k (table rows of ``pos``), k / v
+    appended to cache row ``pos``, attention over rows 0..pos split over 64-key chunks + merge.
+    qkv: [B, (Hq + 2 Hkv) * hd] packed, BEFORE RoPE (left untouched); caches [B, rows, Hkv*hd] contiguous."""
+    _chk2d(qkv, "qkv")
+    B = qkv.shape[0]
+    for t, n in ((k_cache, "k_cache"), (v_cache, "v_cache")):
+        if t.dtype != BF16 or t.dim() != 3 or not t.is_contiguous() or t.shape[0] != B or t.shape[2] != Hkv * hd:
+            raise ValueError(f"attn_decode_fused: {n} must be contiguous bf16 [B, rows, Hkv*hd]")
+    rows = k_cache.shape[1]
+    if v_cache.shape[1] != rows or not 0 <= pos < rows or qkv.shape[1] != (Hq + 2 * Hkv) * hd:
+        raise ValueError("attn_decode_fused: position / shapes")
+    for t in (cos_t, sin_t):
+        if t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != hd // 2 or t.shape[0] <= pos or not t.is_contiguous():
+            raise ValueError("attn_decode_fused: cos / sin tables must be fp32 [positions, hd / 2]")
+    need = B * Hq * (pos // 64 + 1) * (hd + 2)
+    if ws is None:
+        ws = torch.empty(need, dtype=torch.float32, device=qkv.device)
+    if ws.dtype != torch.float32 or ws.numel() < need or not ws.is_contiguous():
+        raise ValueError("attn_decode_fused: workspace too small")
+    if out is None:
+        out = torch.empty((B, Hq * hd), dtype=BF16, device=qkv.device)
+    check(lib.zk_attn_decode_fused(_p(qkv), cos_t[pos].data_ptr(), sin_t[pos].data_ptr(), _p(k_cache), _p(v_cache),
+                                   _p(out), _p(ws), ws.numel(), B, Hq, Hkv, hd, qkv.stride(0), out.stride(0), rows,
+                                   int(pos), float(scale), _stream()), "zk_attn_decode_fused")
+    return out
+
+
 def layernorm_fwd(x, gamma, beta, eps: float, save_stats: bool = True):
     _chk2d(x, "x"); _chk_flat(gamma, "gamma"); _chk_flat(beta, "beta")
     if not x.is_contiguous():
