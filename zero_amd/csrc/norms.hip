@@ -205,6 +205,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, cons
   u32x4 vx[MAXV], vd[MAXV];
   load_row<MAXV>(vx, x + (size_t)row * D, nv, lane);
   load_row<MAXV>(vd, dy + (size_t)row * D, nv, lane);
+  // the residual gradient is requested with the other rows, not after the row reduction (one HBM
+  // round trip per row instead of two)
+  u32x4 vr[MAXV];
+  if (dres) load_row<MAXV>(vr, dres + (size_t)row * D, nv, lane);
   const float rstd = rstd_i[row];
   float s = 0.f;
 #pragma unroll
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, cons
       float fx[8], fd[8], ww[8], r[8], o[8];
       unpack8(vx[i], fx); unpack8(vd[i], fd);
       unpack8(*reinterpret_cast<const u32x4*>(w + (size_t)idx * 8), ww);
-      if (dres) unpack8(*reinterpret_cast<const u32x4*>(dres + (size_t)row * D + (size_t)idx * 8), r);
+      if (dres) unpack8(vr[i], r);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = rstd * (fd[j] * ww[j] - fx[j] * rstd * s) + (dres ? r[j] : 0.f);
       *reinterpret_cast<u32x4*>(dx + (size_t)row * D + (size_t)idx * 8) = pack8(o);
