@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* x, const
 }
 
 template <int MAXV>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* w,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXV <= 6 ? 4 : (MAXV <= 8 ? 2 : 1)))) void rmsnorm_bwd_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* w,
                                                           const float* rstd_i, const bf16_t* dres, bf16_t* dx,
                                                           int rows, int D) {
   const int lane = threadIdx.x & 63;
@@ -223,6 +223,11 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, cons
     }
   }
   s = wave_sum(s) / (float)D;
+  // Only the packed rows stay live across the reduction: the empty asm makes them opaque, so the
+  // compiler unpacks them again below instead of keeping 16 floats per 16-byte chunk in registers
+  // (it did: 256 VGPRs + AGPRs, ONE wave per SIMD, 3.2 TB/s; now 4 waves per SIMD).
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) asm volatile("" : "+v"(vx[i]), "+v"(vd[i]));
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     int idx = lane + 64 * i;
@@ -327,6 +332,8 @@ inline bool bad_dim(int64_t rows, int64_t D) { return rows <= 0 || D <= 0 || (D 
 
 #define DISPATCH_MAXV(D, CALL)                   \
   if ((D) <= 1024) { CALL(2); }                  \
+  else if ((D) <= 2048) { CALL(4); }             \
+  else if ((D) <= 3072) { CALL(6); }             \
   else if ((D) <= 4096) { CALL(8); }             \
   else { CALL(16); }
 
