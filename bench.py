@@ -30,6 +30,29 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.m
 PEAK_HBM_GBS = 8000.0
 
 
+_RESULT_FD = None
+
+
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner to file descriptor 1 when
+    its communicator comes up (from C, past sys.stdout), so descriptor 1 is pointed at stderr for the
+    whole run and the result line is written to a saved duplicate of the real stdout."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_RESULT_FD, line)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +127,9 @@ def pmc_traffic(kernel: str):
 
 def main():
     args = parse()
+    if os.environ.get("ZERO_AMD_BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["ZERO_AMD_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -113,6 +139,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or args.force_dist:
+        _claim_stdout()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if args.force_dist:   # rehearsal of the RCCL path on one GPU: a 1-rank group, collectives still issued
@@ -197,7 +224,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    if rank == 0 and os.environ.get("ZERO_AMD_BENCH_CPROFILE"):
+    if rank == 0 and world == 1 and os.environ.get("ZERO_AMD_BENCH_CPROFILE"):
         import cProfile, pstats
         pr = cProfile.Profile()
         torch.cuda.synchronize()
@@ -231,7 +258,9 @@ def main():
     # variant the library launched (zk_gemm_last_plan), so each group below is ONE kernel symbol of
     # the rocprofv3 table; the roofline line is the symbol with the largest total time.
     roofline = None
-    if rank == 0 and not args.no_kernel_timing:
+    if not args.no_kernel_timing:
+        # EVERY rank takes the two extra steps (they contain the step's collectives: a rank stepping
+        # alone would wait for its peers forever); only rank 0 instruments its launches.
         records = []
 
         class _TimedLib:
@@ -250,13 +279,16 @@ def main():
                 return rc
 
         real_lib = ops.lib
-        ops.lib = _TimedLib(real_lib)
+        if rank == 0:
+            ops.lib = _TimedLib(real_lib)
         try:
             for _ in range(2):
                 step()
             torch.cuda.synchronize()
         finally:
             ops.lib = real_lib
+        barrier()
+    if rank == 0 and not args.no_kernel_timing:
         fam, shp = {}, {}
         for plan, tt, fl, e0, e1, mnk, epi in records:
             ms = e0.elapsed_time(e1)
@@ -344,7 +376,7 @@ def main():
             "mfma_util_step": round(per_gpu * fl_exec / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out), flush=True)
+        _emit(out)
     if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
@@ -426,7 +458,7 @@ def bench_c5(args, world, rank, device):
         pre_ms, dec_ms = t.tolist()
     if rank == 0:
         per_tok = 2.0 * sum(p.numel() for n, p in decoder.named_parameters() if "embed_tokens" not in n)
-        print(json.dumps({
+        _emit(({
             "metric": "zero-shot graft inference on Llama-3.1-70B: decode tokens/sec (one sequence)",
             "value": round(args.new_tokens / (dec_ms * 1e-3), 2), "unit": "tokens/sec", "n_gpus": world,
             "higher_is_better": True, "dtype": "bf16", "data": "synthetic",
@@ -437,7 +469,7 @@ def bench_c5(args, world, rank, device):
                                       "skipped: ONE rank's shard timed on one GPU (compute only)",
                        "weights": "seeded random init", "new_tokens": args.new_tokens},
             "decode_weight_gb_per_token_per_gpu": round(per_tok / 1e9, 2),
-            "decode_weight_stream_gbs": round(per_tok / 1e9 / (dec_ms * 1e-3 / args.new_tokens), 1)}), flush=True)
+            "decode_weight_stream_gbs": round(per_tok / 1e9 / (dec_ms * 1e-3 / args.new_tokens), 1)}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -26,6 +26,17 @@ import torch.nn as nn
 
 from ..functional import GradSink
 
+_DEBUG = os.environ.get("ZERO_AMD_DDP_DEBUG") == "1"
+# (gloo on DEVICE tensors is not a usable rehearsal of this path on a one-GPU box: several of its
+# host-staged exchanges interleaved with kernels hang the device there, tools/probe_gloo_cuda.py
+# reproduces it with torch.matmul alone; RCCL passes the same probe.  gloo rehearsals stay on CPU tensors.)
+
+
+def _dbg(msg: str):
+    import sys, threading
+    r = dist.get_rank() if dist.is_initialized() else 0
+    print(f"[ddp rank {r} {threading.current_thread().name}] {msg}", file=sys.stderr, flush=True)
+
 
 def _pack_groups(params: List[nn.Parameter]) -> List[List[nn.Parameter]]:
     """Keep tensors that are currently back-to-back in one storage (pack_params) together."""
@@ -141,6 +152,8 @@ class FlatGradReducer:
             self._launched[i] = True
             return
         b = self.buckets[i]
+        if _DEBUG:
+            _dbg(f"launch bucket {i} [{b['start']}:{b['end']}) of {len(self.buckets)}")
         self._handles.append(dist.all_reduce(self.flat_grad[b["start"]:b["end"]], op=dist.ReduceOp.SUM,
                                              group=self.pg, async_op=True))
         self._launched[i] = True
@@ -156,7 +169,13 @@ class FlatGradReducer:
             for i in range(len(self.buckets)):
                 if not self._launched[i]:
                     self._launch(i)
-            for h in self._handles:
+            if _DEBUG:
+                _dbg("device sync before the waits ...")
+                torch.cuda.synchronize()
+                _dbg("... device idle")
+            for k, h in enumerate(self._handles):
+                if _DEBUG:
+                    _dbg(f"wait handle {k} of {len(self._handles)}")
                 h.wait()
         self._begin_backward()
 
