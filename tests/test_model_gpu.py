@@ -321,3 +321,27 @@ def test_nan_loss_is_reported_without_a_per_step_sync():
     w.check_and_arm(torch.tensor(float("nan"), device=dev), dev)
     with pytest.raises(ValueError, match="NaN"):
         w.flush()
+
+
+def test_trainable_dgrad_transposed_copy_is_refreshed():
+    """Large-M dgrad through a trainable weight uses a per-step transposed copy (functional.dgrad_trainable):
+    same product as the copy-free path, and the copy follows the weights — through autograd's version counter
+    for in-place torch updates, through the weights epoch for the Trainer's raw-pointer AdamW."""
+    from zero_amd import functional as ZF
+    from zero_amd import ops
+    torch.manual_seed(0)
+    w = torch.nn.Parameter((torch.randn(1024, 512, device=DEV) * 0.05).to(torch.bfloat16))
+    dy = torch.randn(ZF.TRANSPOSED_TRAINABLE_MIN_ROWS, 1024, device=DEV).to(torch.bfloat16)
+    ref = dy.float() @ w.detach().float()
+    a = ZF.dgrad_trainable(dy, w)
+    b = ops.gemm(dy, w, trans_b=True)
+    assert "_zk_wt_step" in w.__dict__                       # the transposed path was taken
+    assert maxrel(a, ref) <= 1e-2 and maxrel(b, ref) <= 1e-2
+    small = ZF.dgrad_trainable(dy[:64], w)                   # few rows: copy-free path, same numbers
+    assert maxrel(small, ref[:64]) <= 1e-2
+    with torch.no_grad():
+        w.mul_(2.0)                                          # torch in-place update: version counter
+    assert maxrel(ZF.dgrad_trainable(dy, w), 2 * ref) <= 1e-2
+    w.data.mul_(2.0)                                         # invisible to autograd, like the fused AdamW kernel
+    ZF.bump_weights_epoch()                                  # ... which is why Trainer.optimizer_step bumps the epoch
+    assert maxrel(ZF.dgrad_trainable(dy, w), 4 * ref) <= 1e-2

@@ -134,6 +134,42 @@ def dgrad(dy2d: torch.Tensor, w: torch.Tensor, owner: Optional[torch.Tensor] = N
     return ops.gemm(dy2d, w, trans_b=True, **kw)
 
 
+# ------------------------------------------------------------------------------------------
+# dgrad through TRAINABLE weights with many rows (C2: 64 x 577 = 36928 tokens): transposing the weight once
+# per optimizer step (8-34 MB of byte traffic per encoder layer) lets dx = dy W run as the NT product on the
+# persistent-ring kernel (~1.0 PF) instead of the transposed-LDS-read kernel (~0.5 PF, tools/bench_enc_gemm.py).
+# Below ~8k rows the products are too small for the copies to pay (C3's encoder, M = 4616, keeps the copy-free
+# path).  The copy is keyed on (weights epoch, tensor version, address): the Trainer's fused AdamW writes the
+# parameters through raw pointers, which no autograd version counter sees, so it bumps WEIGHTS_EPOCH.
+# ------------------------------------------------------------------------------------------
+WEIGHTS_EPOCH = 0
+TRANSPOSED_TRAINABLE_MIN_ROWS = int(os.environ.get("ZERO_AMD_DGRAD_T_MIN_ROWS", "8192"))
+
+
+def bump_weights_epoch():
+    global WEIGHTS_EPOCH
+    WEIGHTS_EPOCH += 1
+
+
+def _step_t(w: torch.Tensor, owner: torch.Tensor) -> torch.Tensor:
+    cache = owner.__dict__.setdefault("_zk_wt_step", {})
+    key = tuple(w.shape)
+    stamp = (WEIGHTS_EPOCH, owner._version, w.data_ptr())
+    hit = cache.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    wt = w.detach().t().contiguous()
+    cache[key] = (stamp, wt)
+    return wt
+
+
+def dgrad_trainable(dy2d: torch.Tensor, w: torch.Tensor, owner: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:
+    """dx = dy @ W for a weight that changes every step (``owner``: the Parameter whose storage ``w`` views)."""
+    if dy2d.shape[0] >= TRANSPOSED_TRAINABLE_MIN_ROWS and w.shape[0] >= 256 and w.shape[1] >= 256:
+        return ops.gemm(dy2d, _step_t(w, w if owner is None else owner), **kw)
+    return ops.gemm(dy2d, w, trans_b=True, **kw)
+
+
 def _wgrad(dy2d, x2d, w: torch.Tensor, need: bool):
     """dW[out,in] = dY^T X, into the slot when there is one.  Returns what autograd should get."""
     if not need:
@@ -329,18 +365,18 @@ class EncoderLayerFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         f32 = lambda n: GradSink.zeros(n, dev)
         # ---- MLP block:  y = xa + fc2(quick_gelu(fc1(LN2(xa))))
-        d_pre = ops.gemm(dy2, f2w, trans_b=True, epilogue=ops.EPI_MUL_DQUICK_GELU, aux_in=pre)
+        d_pre = dgrad_trainable(dy2, f2w, epilogue=ops.EPI_MUL_DQUICK_GELU, aux_in=pre)
         g_f2w = _wgrad(dy2, act, f2w, nig[15])
         g_f2b = _bias_grad(dy2, f2b, nig[16])
         g_f1w = _wgrad(d_pre, h2, f1w, nig[13])
         g_f1b = _bias_grad(d_pre, f1b, nig[14])
-        d_h2 = ops.gemm(d_pre, f1w, trans_b=True)
+        d_h2 = dgrad_trainable(d_pre, f1w)
         need_ln2 = nig[11] or nig[12]
         dg2, db2 = (f32(D), f32(D)) if need_ln2 else (None, None)
         dxa = ops.layernorm_bwd(d_h2, xa, l2w, mean2, rstd2, dres=dy2, dgamma=dg2, dbeta=db2)
         g_l2w, g_l2b = _vec_grad(dg2, l2w, nig[11]), _vec_grad(db2, l2b, nig[12])
         # ---- attention block:  xa = x + out(attn(qkv(LN1(x))))
-        d_ao = ops.gemm(dxa, ow, trans_b=True)
+        d_ao = dgrad_trainable(dxa, ow)
         g_ow = _wgrad(dxa, ao, ow, nig[9])
         g_ob = _bias_grad(dxa, ob, nig[10])
         d_qkv = torch.empty_like(qkv)
@@ -372,7 +408,7 @@ class EncoderLayerFn(torch.autograd.Function):
         g_l1w = g_l1b = None
         if need_dx or nig[1] or nig[2]:
             if wqkv is not None:
-                d_h1 = ops.gemm(d_qkv, wqkv, trans_b=True)
+                d_h1 = dgrad_trainable(d_qkv, wqkv, owner=qw)
             else:
                 d_h1 = ops.gemm(d_qkv[:, :D], qw, trans_b=True)
                 ops.gemm(d_qkv[:, D:2 * D], kw, trans_b=True, out=d_h1, accumulate=True)
@@ -529,12 +565,12 @@ class AdapterFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        d_pre = ops.gemm(dy2, w2, trans_b=True, epilogue=ops.EPI_MUL_DGELU_ERF, aux_in=pre)
+        d_pre = dgrad_trainable(dy2, w2, epilogue=ops.EPI_MUL_DGELU_ERF, aux_in=pre)
         g_w2 = _wgrad(dy2, act, w2, nig[3])
         g_b2 = _bias_grad(dy2, b2, nig[4])
         g_w0 = _wgrad(d_pre, x2, w0, nig[1])
         g_b0 = _bias_grad(d_pre, b0, nig[2])
-        dx = ops.gemm(d_pre, w0, trans_b=True) if nig[0] else None
+        dx = dgrad_trainable(d_pre, w0) if nig[0] else None
         if dx is not None:
             dx = dx.view(*dy.shape[:-1], w0.shape[1])
         GradSink.flush()

@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import ops
 from .distributed.ddp import FlatGradReducer
-from .functional import GradSink, ZeroArena
+from .functional import GradSink, ZeroArena, bump_weights_epoch
 
 
 class Trainer:
@@ -84,6 +84,7 @@ class Trainer:
     def optimizer_step(self):
         r, cfg = self.reducer, self.cfg
         self.global_step += 1
+        bump_weights_epoch()           # the fused AdamW below writes the parameters through raw pointers
         self.sumsq.zero_()
         max_norm = float(cfg.grad_clip)
         if max_norm > 0:
@@ -119,3 +120,4 @@ class Trainer:
                 self.v[o:o + n].copy_(sd["exp_avg_sq"][name].reshape(-1))
         self.global_step = int(sd.get("global_step", 0))
         self._micro = int(sd.get("micro", 0))
+        bump_weights_epoch()
