@@ -1135,6 +1135,14 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
   if (plain && workspace && g_force_splits != 1) {
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
     int64_t sp = g_force_splits > 1 ? g_force_splits : (tiles <= 300 && K >= 2048 ? 1024 / tiles : 1);
+    if (g_force_splits <= 1 && tiles > 300 && tiles <= 1024 && K >= 4096) {
+      // mid-size outputs with a long contraction (the adapter's 3072 x 3072 weight gradient: 576 tiles are
+      // 1.125 rounds of the 512 block slots): the smallest split that fills its last round, if the
+      // unsplit grid wastes more than a tenth over it
+      auto eff = [&](int64_t s_) { const double r = (double)(tiles * s_) / 512.0; return r / (double)(int64_t)(r + 0.999999); };
+      for (int64_t s_ = 2; s_ <= 8 && K / s_ >= 1024; ++s_)
+        if (eff(s_) >= 0.88 && eff(s_) > eff(1) + 0.1) { sp = s_; break; }
+    }
     if (sp > 16) sp = 16;
     while (sp > 1 && (K / sp < 512 || sp * M * N * 4 > workspace_bytes)) --sp;
     if (sp > 1) {
