@@ -902,7 +902,6 @@ __global__ __launch_bounds__(512) void gemm_pring_kernel(GemmArgs g) {
     if constexpr (COUNT > 7) issue_part(std::integral_constant<int, (FIRST + 7) % SPT>{});
     if constexpr (COUNT > 8) issue_part(std::integral_constant<int, (FIRST + 8) % SPT>{});
   };
-  using T_ = std::true_type;
   // prologue: fill the ring (host guarantees nk >= 4: no tile boundary in here), wait for K-tile 0
   issue_group(std::integral_constant<int, 0>{}, std::integral_constant<int, NSLOT>{});
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - SPT) * PER) : "memory");
