@@ -278,6 +278,28 @@ def main():
                 records.append((self._real.zk_gemm_last_plan(), (ta, tb), 2.0 * M * N * K, e0, e1, (M, N, K), epi))
                 return rc
 
+        # the bandwidth-bound kernels of the same two steps, each launch bracketed the same way; algorithmic
+        # bytes per launch from its arguments (read + write of every operand row once)
+        bw_records = []
+
+        def _bw(name, nbytes_of):
+            def call(self, *a):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = getattr(self._real, name)(*a)
+                e1.record()
+                bw_records.append((name, float(nbytes_of(a)), e0, e1))
+                return rc
+            setattr(_TimedLib, name, call)
+
+        _bw("zk_rmsnorm_fwd", lambda a: a[4] * a[5] * 4)
+        _bw("zk_rmsnorm_bwd", lambda a: a[6] * a[7] * (8 if a[4] else 6))
+        _bw("zk_layernorm_fwd", lambda a: a[6] * a[7] * 4)
+        _bw("zk_layernorm_bwd", lambda a: a[9] * a[10] * ((6 if a[6] else 4) + (2 if a[5] else 0)))
+        _bw("zk_rope", lambda a: a[3] * a[5] * a[6] * 4)
+        _bw("zk_cross_entropy", lambda a: a[4] * a[5] * (4 if a[3] else 2))
+        _bw("zk_adamw_step", lambda a: a[4] * 22)
+
         real_lib = ops.lib
         if rank == 0:
             ops.lib = _TimedLib(real_lib)
@@ -315,6 +337,16 @@ def main():
                     "kernels": {plan_name(k): {"n": v["n"] // 2, "ms": round(v["ms"] / 2, 2),
                                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
                                 for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}}
+        bwf = {}
+        for name, nb, e0, e1 in bw_records:
+            d_ = bwf.setdefault(name, dict(n=0, ms=0.0, bytes=0.0))
+            d_["n"] += 1; d_["ms"] += e0.elapsed_time(e1); d_["bytes"] += nb
+        # achieved = algorithmic bytes / launch time INSIDE the step (operands are often still in the 256 MB
+        # Infinity Cache there; the cold-operand HBM rates are profiles/r01_bandwidth_kernels.json)
+        roofline["hbm_kernels"] = {k[3:]: {"n": v["n"] // 2, "ms": round(v["ms"] / 2, 3),
+                                           "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9),
+                                           "frac_of_8TBps": round(v["bytes"] / (v["ms"] * 1e-3) / 8e12, 3)}
+                                   for k, v in sorted(bwf.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0}
 
     # ---- CPU baseline: the oracle on the host cores, rank 0, N = 1 only, bounded sample
     cpu_baseline = None
