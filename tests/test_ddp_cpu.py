@@ -50,11 +50,19 @@ def _worker(rank, world, port, q):
                 self.q, self.k, self.v = Linear(8, 8), Linear(8, 8), Linear(8, 8)
                 pack_params([self.q.weight, self.k.weight, self.v.weight])
                 self.o = Linear(8, 16)
-        torch.manual_seed(0)
+        torch.manual_seed(100 + rank)                       # replicas seeded DIFFERENTLY on purpose
         m = M()
         r = FlatGradReducer(m, bucket_bytes=256)
         assert r.world == 2 and len(r.buckets) >= 2
         params = list(r.params)
+        # construction broadcast rank 0's parameters (DDP's _sync_module_states, ref:train.py:367)
+        mine = r.flat_param.clone()
+        both = [torch.empty_like(mine) for _ in range(2)]
+        dist.all_gather(both, mine)
+        assert torch.equal(both[0], both[1]), "replicas differ after FlatGradReducer construction"
+        torch.manual_seed(100)
+        m0 = M()
+        assert torch.equal(m.o.weight.detach(), m0.o.weight.detach().to(m.o.weight.dtype))
 
         def write(p, val, accumulate):
             if accumulate and p._zk_dirty:
@@ -87,6 +95,40 @@ def _worker(rank, world, port, q):
         r.finish_backward()
         for p in params:
             assert torch.all(p._zk_grad.float() == 6.0)                   # (1+1) + (2+2)
+
+        # step 3: the ranks produce their gradients in DIFFERENT orders and rank 1 never writes a parameter
+        # of the FIRST bucket (an unused parameter): collectives must still pair up bucket by
+        # bucket (issued in index order on every rank), the skipped slot counts as zero
+        r.begin_step()
+        skipped = r.buckets[0]["params"][0]
+        order = list(params) if rank == 0 else list(reversed(params))
+        for p in order:
+            if rank == 1 and p is skipped:
+                continue
+            write(p, float(rank + 1), False)
+        if rank == 1:
+            assert not any(r._launched), "a later bucket was launched ahead of the unfinished first one"
+        r.finish_backward()
+        for p in params:
+            want = 1.0 if p is skipped else 3.0
+            assert torch.all(p._zk_grad.float() == want), (r.names[id(p)], p._zk_grad)
+
+        # a second write after the bucket went out would be lost: it must raise, not corrupt silently
+        r.begin_step()
+        first = r.buckets[0]["params"]
+        for p in first:
+            write(p, 1.0, False)
+        try:
+            write(first[0], 1.0, True)
+            raised = False
+        except RuntimeError:
+            raised = True
+        assert raised
+        first_ids = {id(p) for p in first}
+        for p in params:
+            if id(p) not in first_ids:
+                write(p, 1.0, False)
+        r.finish_backward()
         r.close()
         dist.destroy_process_group()
         q.put((rank, "ok"))

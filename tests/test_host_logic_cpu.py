@@ -61,7 +61,11 @@ def test_surgery_on_modules_matches_oracle_map():
         def __init__(self, i):
             super().__init__()
             self.idx = i
-    for n, ranges, nt in ((28, (list(range(16, 27)),), 1), (12, ([2, 3, 4], [7, 8, 9]), 1), (32, (list(range(17, 31)),), 1)):
+    from zero_amd.build_decoder import surgery_plan
+    # nt = 2: the reference's shrinking-list walk (build_decoder.py:305-316) keeps entries 0 and 2 of each range
+    assert surgery_plan(12, ([2, 3, 4, 5], [8, 9, 10]), 2) == ([2, 4, 8, 10], [3, 5, 9])
+    for n, ranges, nt in ((28, (list(range(16, 27)),), 1), (12, ([2, 3, 4], [7, 8, 9]), 1), (32, (list(range(17, 31)),), 1),
+                          (80, (list(range(40, 79)),), 1), (12, ([2, 3, 4, 5], [8, 9, 10]), 2)):
         model = types.SimpleNamespace(model=types.SimpleNamespace(layers=torch.nn.ModuleList([L(i) for i in range(n)])))
         cfg = types.SimpleNamespace(enable_translator=True, translators_range=ranges, num_translators=nt,
                                     decoder_hf_model_name="t")
@@ -69,8 +73,9 @@ def test_surgery_on_modules_matches_oracle_map():
         build_surrogate_model(cfg, model, num_hidden_layers=n)
         kept = [l.idx for l in model.model.layers]
         assert kept == zo.surrogate_layer_map(n, ranges, nt)
-        first = sorted(ranges[0])[0]
-        assert type(model.model.layers[kept.index(first)]).__name__ == "Translator"
+        tr, _ = surgery_plan(n, ranges, nt)
+        for l in model.model.layers:
+            assert (type(l).__name__ == "Translator") == (l.idx in tr) and isinstance(l, L)
 
 
 def test_reduce_sum_identity_backward_single_rank():

@@ -496,9 +496,15 @@ def test_cross_entropy(rows, V):
     assert acc[1].item() == (tgt != -100).sum().item()
     assert relerr(dl, lf.grad) < 8e-3
     # in place
-    l2 = logits.clone()
-    ops.cross_entropy(l2, tgt_d, torch.zeros(2, device=DEV), l2)
-    assert torch.equal(l2, dl)
+    # in place (LMHeadLossFn's mode): same gradient AND the same loss — the target logit must be read
+    # before any wave overwrites it with softmax - onehot; repeated so a timing-dependent race shows
+    for _ in range(4):
+        l2 = logits.clone()
+        acc2 = torch.zeros(2, device=DEV)
+        ops.cross_entropy(l2, tgt_d, acc2, l2)
+        assert torch.equal(l2, dl)
+        assert abs(acc2[0].item() - acc[0].item()) <= 1e-5 * abs(acc[0].item())
+        assert acc2[1].item() == acc[1].item()
 
 
 def test_sumsq_adamw_f32tobf16():

@@ -7,9 +7,6 @@ hub weights and the tokenizer cannot be fetched offline; ``tokenizer`` is None u
 ``cfg.tokenizer`` supplies one."""
 from __future__ import annotations
 
-from copy import deepcopy
-
-import numpy as np
 import torch
 
 from .configs.config_base import LLAMA_SHAPES
@@ -44,53 +41,74 @@ def load_hf_llama3(cfg: object):
     return num_embd, model, tokenizer, LlamaDecoderLayer, is_giant_model
 
 
+def surgery_plan(num_hidden_layers: int, translators_range, num_translators: int):
+    """What ref:build_decoder.py:283-330 does to the layer list, as two sets of ORIGINAL layer indices:
+    (layers re-classed to ``Translator``, layers removed).
+
+    Per range (sorted, consecutive, inside [0, num_hidden_layers)): the reference walks ``i`` over
+    ``range(num_translators)``, re-classes entry ``i`` of the range list and deletes that entry from the list
+    before taking the next one, so the layers it keeps as translators are entries 0, 2, 4, ... of the range;
+    everything else in the range is popped from the model."""
+    translators, removed = [], []
+    last = -1
+    for rng in translators_range:
+        rng = sorted(int(v) for v in rng)
+        if any(b - a != 1 for a, b in zip(rng, rng[1:])):
+            raise AssertionError("translators_range should be consecutive without skipping layers")
+        if not (0 <= rng[0] < rng[-1] < num_hidden_layers):
+            raise AssertionError(f"translators_range should be in the range of [0, {num_hidden_layers})")
+        if num_translators > len(rng):
+            raise AssertionError("num_translators should be less than or equal to the number of layers in "
+                                 f"translators_range: {len(rng)}")
+        if rng[0] <= last:
+            raise AssertionError("translators_range entries must be disjoint and in ascending order")
+        last = rng[-1]
+        picks = [2 * i for i in range(num_translators)]
+        if picks and picks[-1] >= len(rng):
+            raise IndexError("list index out of range")      # what the reference's shrinking-list walk raises
+        kept = {rng[j] for j in picks}
+        translators += sorted(kept)
+        removed += [v for v in rng if v not in kept]
+    return translators, removed
+
+
 def build_surrogate_model(cfg, model, model_attr="model", num_hidden_layers=-1):
-    """ref:build_decoder.py:268-335: per range, the first ``num_translators`` layers are
-    re-classed to ``Translator`` in place and the rest popped (offsets as in the reference)."""
-    model_name = getattr(cfg, "decoder_hf_model_name", "decoder")
-    if cfg.enable_translator:
-        print("start converting to surrogate model")
-        print_model_numel(model, model_name="[orig] " + str(model_name))
-        translators_range = [list(r) for r in deepcopy(cfg.translators_range)]
-        for range_idx, trans_range in enumerate(translators_range):
-            trans_range.sort()
-            assert (np.sum(np.diff(trans_range) == 1) == len(trans_range) - 1), \
-                "translators_range should be consecutive without skipping layers"
-            assert np.all(np.array(trans_range) >= 0)
-            assert 0 <= min(trans_range) < max(trans_range) < num_hidden_layers, \
-                f"translators_range should be in the range of [0, {num_hidden_layers})"
-            assert cfg.num_translators <= len(trans_range), \
-                f"num_translators should be less than or equal to the number of layers in translators_range: {len(trans_range)}"
-            index_offset = 0
-            if range_idx > 0:
-                index_offset += sum(len(translators_range[i]) for i in range(range_idx))
-            for i in range(cfg.num_translators):
-                translator_layer_id = trans_range[i]
-                print(f"- mv layer {translator_layer_id:>3} to translator -- actual layer {translator_layer_id - index_offset:>3}")
-                model = rename_layer_to_translator(model, translator_layer_id - index_offset, model_attr=model_attr)
-                trans_range.pop(i)
-            for layer_id in trans_range:
-                print(f"- rm layer {layer_id:>3}                -- actual layer {layer_id - index_offset:>3}")
-                model = remove_layer_from_model(model, layer_id - index_offset, model_attr=model_attr)
-                index_offset += 1
-        print_model_numel(model, model_name="[srgt] " + str(model_name))
-    else:
-        print_model_numel(model, model_name=str(model_name))
+    """Truncate ``model`` to the surrogate (ref:build_decoder.py:268-335; 28→18, 32→19, 80→42 layers for the
+    shipped ranges): translator layers keep their weights and position but read as class ``Translator``, the other
+    layers of each range leave the ``ModuleList``.  ``config.num_hidden_layers`` is left alone, as there."""
+    name = str(getattr(cfg, "decoder_hf_model_name", "decoder"))
+    if not cfg.enable_translator:
+        print_model_numel(model, model_name=name)
+        return model
+    print_model_numel(model, model_name="[orig] " + name)
+    translators, removed = surgery_plan(num_hidden_layers, cfg.translators_range, cfg.num_translators)
+    gone = 0                                   # layers already removed below the one being handled
+    todo = sorted([(i, "mv") for i in translators] + [(i, "rm") for i in removed])
+    for orig, what in todo:
+        slot = orig - gone
+        if what == "mv":
+            print(f"surrogate: layer {orig} (slot {slot}) -> Translator")
+            rename_layer_to_translator(model, slot, model_attr=model_attr)
+        else:
+            print(f"surrogate: layer {orig} (slot {slot}) removed")
+            remove_layer_from_model(model, slot, model_attr=model_attr)
+            gone += 1
+    print_model_numel(model, model_name="[srgt] " + name)
     return model
 
 
 def rename_layer_to_translator(model: torch.nn.Module, layer_id: int, model_attr="model"):
-    """Same numerics, new class name ``Translator`` sharing the layer's __dict__
-    (ref:build_decoder.py:338-357)."""
+    """The layer in slot ``layer_id`` becomes an instance of a fresh subclass named ``Translator``
+    (ref:build_decoder.py:338-357): same parameters, buffers and forward, only ``type(layer).__name__`` —
+    what ``func_optim_filter`` and class-based wrapping policies look at — changes."""
     layers = getattr(model, model_attr).layers
     layer = layers[layer_id]
-    Translator = type("Translator", (type(layer),), {})
-    translator = Translator.__new__(Translator)
-    translator.__dict__.update(layer.__dict__)
-    layers[layer_id] = translator
+    layer.__class__ = type("Translator", (type(layer),), {})
     return model
 
 
 def remove_layer_from_model(model: torch.nn.Module, layer_id: int, model_attr="model"):
-    getattr(model, model_attr).layers.pop(layer_id)
+    """ref:build_decoder.py:360-362."""
+    layers = getattr(model, model_attr).layers
+    del layers[layer_id]
     return model

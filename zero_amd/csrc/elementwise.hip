@@ -241,6 +241,9 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const bf16_t* logits
     if (dx) for (int i = threadIdx.x; i < nv; i += 256) *reinterpret_cast<u32x4*>(dx + (size_t)i * 8) = u32x4{0u, 0u, 0u, 0u};
     return;
   }
+  // dlogits may alias logits: the target logit is read HERE, before any wave can have reached pass 2
+  // (block_sum has no trailing barrier, so a read after pass 1 would race with other waves' stores).
+  const float xt = bf2f(x[tgt]);
   float m = -INFINITY, s = 0.f;
   for (int i = threadIdx.x; i < nv; i += 256) {
     float f[8];
@@ -259,7 +262,6 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const bf16_t* logits
   s = (m == -INFINITY) ? 0.f : s * __expf(m - gm);
   const float gs = block_sum(s, red);
   if (threadIdx.x == 0) {
-    float xt = bf2f(x[tgt]);
     atomicAdd(loss_sum, logf(gs) + gm - xt);
     atomicAdd(loss_sum + 1, 1.0f);
   }

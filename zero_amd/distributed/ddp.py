@@ -10,8 +10,16 @@ Design (MI355X / RCCL over xGMI):
     straight into the gradient slots (functional.GradSink), so there is no bucket copy;
   * buckets are contiguous slices (~25 MB, DDP's default, about one encoder layer each);
     a bucket's all-reduce (SUM; the 1/world average is folded into the optimizer kernel) is
-    launched asynchronously the moment its last slot has been written, overlapping the
-    remaining backward;
+    launched asynchronously once its last slot AND every earlier bucket have been written,
+    overlapping the remaining backward.  Collectives are therefore issued in bucket-index order on
+    every rank, whatever order (or subset) of gradients a rank produced — RCCL pairs collectives by
+    issue order, and a rank whose batch leaves a parameter unused (the case the reference passes
+    find_unused_parameters=True for) must not reorder them; buckets with unwritten
+    slots are flushed, zero-filled, in index order by finish_backward();
+  * construction broadcasts rank 0's parameters (what DDP(...) does at ref:train.py:367), so replicas
+    start identical even if the ranks were seeded differently;
+  * one gradient write per parameter and backward (the layer nodes of functional.py write each slot
+    once): a second write after the bucket's all-reduce was launched would be lost, so it raises;
   * gradient accumulation: ``no_sync()`` suppresses the launches; slots accumulate in place.
 """
 from __future__ import annotations
@@ -97,6 +105,10 @@ class FlatGradReducer:
                 p._zk_grad = self.flat_grad[o:o + n]
                 p._zk_dirty = False
                 self.offset[id(p)] = o
+        if self.world > 1:
+            # DDP's _sync_module_states: every replica starts from rank 0's trainable parameters
+            src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+            dist.broadcast(self.flat_param, src=src, group=process_group)
         # contiguous buckets
         self.buckets: List[dict] = []
         cur = dict(start=0, end=0, params=[])
@@ -128,6 +140,7 @@ class FlatGradReducer:
         self._pending = [len(b["params"]) for b in self.buckets]
         self._seen = set()
         self._launched = [False] * len(self.buckets)
+        self._next = 0                      # first bucket whose all-reduce has not been issued
         self._handles = []
 
     @contextmanager
@@ -140,12 +153,20 @@ class FlatGradReducer:
 
     def _on_grad(self, p):
         i = self.bucket_of.get(id(p))
-        if i is None or id(p) in self._seen:
+        if i is None:
+            return
+        if id(p) in self._seen:
+            if self._launched[i] and self._sync:
+                raise RuntimeError(f"gradient of {self.names[id(p)]} written again after its bucket's all-reduce "
+                                   "was launched (one write per parameter and backward is assumed)")
             return
         self._seen.add(id(p))
         self._pending[i] -= 1
-        if self._pending[i] == 0 and self._sync:
-            self._launch(i)
+        if self._sync:
+            # issue only the contiguous ready prefix: same collective order on every rank
+            while self._next < len(self.buckets) and self._pending[self._next] == 0:
+                self._launch(self._next)
+                self._next += 1
 
     def _launch(self, i):
         if self._launched[i] or (self.world == 1 and not self._force):
@@ -166,9 +187,9 @@ class FlatGradReducer:
                 p._zk_grad.zero_()
                 p._zk_dirty = True
         if self._sync:
-            for i in range(len(self.buckets)):
-                if not self._launched[i]:
-                    self._launch(i)
+            for i in range(self._next, len(self.buckets)):     # the rest, in index order
+                self._launch(i)
+            self._next = len(self.buckets)
             if _DEBUG:
                 _dbg("device sync before the waits ...")
                 torch.cuda.synchronize()

@@ -204,6 +204,11 @@ def _upload(plan, device, keys):
 
 def forward_from_ids(self, cfg, imgs: List[torch.Tensor], input_ids, targets, img_id: int, pad_id: int,
                      return_aux: bool = False):
+    if getattr(cfg, "enable_balance_loss_weights", False):
+        # engine:243-255,299-301,460-550 multiply the per-token loss by batch-mean response weights (two extra
+        # MAX / SUM all-reduces); off in every shipped config (config_base.py:140) and not built here — a config
+        # that turns it on must not silently train on a different objective
+        raise NotImplementedError("enable_balance_loss_weights (_calc_loss_weights_with_batchmean) is not implemented")
     device = imgs[0].device
     rows, split_sizes, T = self._encode_rows(imgs)                       # engine:49
     plan = build_plan(input_ids, targets, [p * T for p in split_sizes], img_id, pad_id, cfg.max_seq_len)
