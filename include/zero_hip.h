@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ZK_ABI_VERSION 1
+#define ZK_ABI_VERSION 2
 int zk_abi_version(void);
 
 /* ---- GEMM -------------------------------------------------------------------------
@@ -84,15 +84,27 @@ int zk_gemv_fused_bf16(const void* x, const void* W, void* y, int64_t M, int64_t
                        int64_t ldx, int64_t ldw, int64_t ldy, const void* residual, int64_t ldr,
                        int xmode, const void* ln_w, float eps, hipStream_t stream);
 
-/* Tuning hook (no counterpart in the reference): force the block tile of zk_gemm_bf16.
- * -1 = built-in cost model (default), 0 = 128x128, 1 = 256x128, 2 = 256x256;
- * 10/11 = LDS-DMA for all operands / registers for transposed ones (default);
- * 20/21 = 256x128 ring kernel off/on, 40/41 = lean DMA addressing off/on,
- * 50/51 = persistent slot ring off/on (default on: one workgroup per CU walks its tiles),
- * 60 + b = m-tiles per band of its tile order (60 = default), 100000 + t = its start stagger in
- * 10 ns ticks per phase step (99999 = built-in policy),
- * 100 = split-K heuristic (default), 101 = no split-K, 102..116 = force that many splits. */
-int zk_gemm_set_tile(int cfg);
+/* The same product under an explicit kernel plan (no counterpart in the reference: tests exercise every kernel
+ * variant through it, benchmarks A/B them).  The library keeps no mutable tuning state: zk_gemm_bf16 is this call
+ * with plan = NULL (built-in cost model).  Fields, -1 / 0 = built-in choice unless stated:
+ *   tile        -1 cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256, 3 = 128x96, 4 = 384x192 (NT ring only)
+ *   splits      0 heuristic, 1 never split K, 2..16 force that many splits (plain products with a workspace)
+ *   stage_mode  -1 default (1), 0 LDS-DMA for every operand, 1 registers for transposed operands
+ *   ring        -1 default (1), 0 / 1: 3-stage ring kernel for NT products on the 256x128 tile off / on
+ *   lean        -1 default (1), 0 / 1: lean DMA addressing off / on
+ *   pring       -1 default (1), 0 / 1: persistent slot ring off / on (on: one workgroup per CU walks its tiles)
+ *   band        0 default, 1..16 m-tiles per band of the persistent kernel's tile order
+ *   phase_delay -1 built-in policy, else the persistent kernel's start stagger in 10 ns ticks per phase step
+ *   ablation    0; timing-only modes with WRONG results (1 no MFMA, 2 no DMA, 3 no epilogue) are accepted only by
+ *               a library built with -DZK_ABLATION (tools/ring_modes.py), -22 otherwise. */
+typedef struct {
+  int tile, splits, stage_mode, ring, lean, pring, band, phase_delay, ablation;
+} zk_gemm_plan_t;
+int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                      int64_t ldb, int64_t ldc, int transA, int transB, int epilogue, const void* bias,
+                      const void* residual, int64_t ldr, void* aux_out, const void* aux_in, int64_t ldaux,
+                      float alpha, const float* alpha_dev, int accumulate, void* workspace,
+                      int64_t workspace_bytes, const zk_gemm_plan_t* plan, hipStream_t stream);
 
 /* Measurement hook (no counterpart in the reference): which kernel variant this thread's last
  * zk_gemm_bf16 call launched, so a benchmark can attribute its event timings to the kernel symbols a

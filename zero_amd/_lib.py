@@ -25,7 +25,7 @@ SIGNATURES = {
     "zk_gemm_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _P, _P, _L, _P, _P, _L, _F, _P, _I, _P, _L, _P],
     "zk_gemv_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _P, _L, _P],
     "zk_gemv_fused_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _P, _L, _I, _P, _F, _P],
-    "zk_gemm_set_tile": [_I],
+    "zk_gemm_bf16_plan": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _P, _P, _L, _P, _P, _L, _F, _P, _I, _P, _L, _P, _P],
     "zk_gemm_last_plan": [],
     "zk_attn_fwd": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "zk_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
@@ -61,7 +61,7 @@ for _name, _args in SIGNATURES.items():
     _fn.argtypes = _args
     _fn.restype = c_int
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 if lib.zk_abi_version() != ABI_VERSION:
     raise ImportError("libzero_hip.so ABI version mismatch; rebuild with `make -C zero_amd/csrc`")
 
@@ -74,6 +74,16 @@ class DecodeLayer(ctypes.Structure):
                 [("attn_ws_floats", c_int64)])
 
 
+class GemmPlan(ctypes.Structure):
+    """zk_gemm_plan_t of include/zero_hip.h (per-call kernel plan; the library holds no tuning state)."""
+    _fields_ = [(n, c_int) for n in ("tile", "splits", "stage_mode", "ring", "lean", "pring", "band", "phase_delay",
+                                     "ablation")]
+
+    @classmethod
+    def default(cls):
+        return cls(-1, 0, -1, -1, -1, -1, 0, -1, 0)
+
+
 class ZeroHipError(RuntimeError):
     pass
 
@@ -81,4 +91,4 @@ class ZeroHipError(RuntimeError):
 def check(rc: int, what: str):
     if rc != 0:
         raise ZeroHipError(f"{what} failed with code {rc} "
-                           f"({'invalid argument / unsupported shape' if rc == -22 else 'launch failure'})")
+                           f"({ {-22: 'invalid argument / unsupported shape', -7: 'beyond the stated size limit'}.get(rc, 'launch failure')})")

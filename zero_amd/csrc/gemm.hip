@@ -1008,14 +1008,18 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* slab, b
 
 #ifndef ZK_KERNEL_PROBE   // (probe builds instantiate one kernel for disassembly: tools/probe_kernel.sh)
 namespace {
-int g_force_tile = -1;   // tuning hook: -1 = cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256
-int g_force_splits = 0;  // tuning hook: 0 = heuristic, 1 = never split K, n > 1 = force n splits
-int g_lean = 1;          // experiment hook: 0 = never use the lean DMA path
-int g_ring_mode = 0;     // experiment hook: 1 = ring kernel without MFMAs, 2 = without DMA (wrong results)
-int g_ring = 1;          // tuning hook: 1 = 3-stage ring kernel for NT products on the 256x128 tile
-int g_phase_delay = -1;  // tuning hook: persistent kernel start stagger, 10 ns ticks per phase step (-1 = policy below)
-int g_band = 0;          // tuning hook: m-tiles per band of the persistent kernel's tile order (0 = default)
-int g_pring = 1;         // tuning hook: 1 = persistent slot ring for the large NT products (0 = one workgroup per tile)
+// Per-call plan (zk_gemm_plan_t of the header, or its defaults): the library keeps NO mutable tuning state.
+struct Plan {
+  int tile = -1;         // -1 = cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256, 3 = 128x96, 4 = 384x192
+  int splits = 0;        // 0 = heuristic, 1 = never split K, n > 1 = force n splits
+  int stage_mode = 1;    // 0 = LDS-DMA for every operand, 1 = registers for transposed operands
+  int ring = 1;          // 1 = 3-stage ring kernel for NT products on the 256x128 tile
+  int ring_mode = 0;     // ablations (ZK_ABLATION builds only): 1 = ring without MFMAs, 2 = without DMA, 3 = no epilogue
+  int lean = 1;          // 0 = never use the lean DMA path
+  int pring = 1;         // 1 = persistent slot ring for the large NT products (0 = one workgroup per tile)
+  int band = 0;          // m-tiles per band of the persistent kernel's tile order (0 = default)
+  int phase_delay = -1;  // persistent kernel start stagger, 10 ns ticks per phase step (-1 = built-in policy)
+};
 int g_num_cu[16] = {0};
 thread_local int g_last_plan = -1;   // kernel variant of this thread's last zk_gemm_bf16 call (zk_gemm_last_plan)
 
@@ -1029,15 +1033,14 @@ int num_cus() {
   }
   return g_num_cu[dev];
 }
-int g_stage_mode = 1;    // tuning hook: 0 = LDS-DMA for every operand, 1 = registers for transposed operands
 
 template <int BM, int BN, int WM_, int WN_>
-void launch_cfg(const GemmArgs& g0, int transA, int transB, hipStream_t stream) {
+void launch_cfg(const GemmArgs& g0, int transA, int transB, hipStream_t stream, const Plan& P) {
   GemmArgs g = g0;
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
   dim3 grid(g.tiles_m * g.tiles_n * g.splits), block(64 * WM_ * WN_);
-  const bool reg = g_stage_mode == 1;
+  const bool reg = P.stage_mode == 1;
 #define ZK_LAUNCH(TA_, TB_, STG_) hipLaunchKernelGGL((gemm_kernel<TA_, TB_, BM, BN, WM_, WN_, STG_>), grid, block, 0, stream, g)
   if (!transA && !transB) ZK_LAUNCH(false, false, 0);
   else if (transA && !transB) { if (reg) ZK_LAUNCH(true, false, 1); else ZK_LAUNCH(true, false, 0); }
@@ -1049,12 +1052,12 @@ void launch_cfg(const GemmArgs& g0, int transA, int transB, hipStream_t stream) 
 }
 
 // Tile choice: time ~ rounds(tiles / concurrent blocks) x tile area / relative efficiency.
-int choose_tile(int64_t M, int64_t N, int transA, int transB, bool need_tn4 = false) {
-  const bool nt_ring = !transA && !transB && g_ring;
-  if (g_force_tile >= 0) {
-    if (g_force_tile == 3 && (transB || need_tn4)) return 0;
-    if (g_force_tile == 4 && (!nt_ring || need_tn4)) return 2;
-    return g_force_tile;
+int choose_tile(int64_t M, int64_t N, int transA, int transB, bool need_tn4, const Plan& P) {
+  const bool nt_ring = !transA && !transB && P.ring;
+  if (P.tile >= 0) {
+    if (P.tile == 3 && (transB || need_tn4)) return 0;
+    if (P.tile == 4 && (!nt_ring || need_tn4)) return 2;
+    return P.tile;
   }
   const int bm[5] = {128, 256, 256, 128, 384}, bn[5] = {128, 128, 256, 96, 192};
   const double slots[5] = {512.0, 256.0, 256.0, 512.0, 256.0};   // two 4-wave blocks or one 8-wave block per CU
@@ -1076,27 +1079,36 @@ int choose_tile(int64_t M, int64_t N, int transA, int transB, bool need_tn4 = fa
 
 extern "C" int zk_gemm_last_plan(void) { return g_last_plan; }
 
-extern "C" int zk_gemm_set_tile(int cfg) {
-  // cfg in [-1, 2] selects the tile; cfg = 10 / 11 selects the staging mode (0 / 1)
-  if (cfg == 10 || cfg == 11) { g_stage_mode = cfg - 10; return ZK_OK; }
-  if (cfg == 20 || cfg == 21) { g_ring = cfg - 20; return ZK_OK; }
-  if (cfg >= 30 && cfg <= 33) { g_ring_mode = cfg - 30; return ZK_OK; }
-  if (cfg == 40 || cfg == 41) { g_lean = cfg - 40; return ZK_OK; }
-  if (cfg == 50 || cfg == 51) { g_pring = cfg - 50; return ZK_OK; }
-  if (cfg >= 60 && cfg <= 76) { g_band = cfg - 60; return ZK_OK; }   // 60 = default
-  if (cfg >= 100000) { g_phase_delay = cfg - 100000; return ZK_OK; }    // start stagger in 10 ns ticks (+ phases << 20)
-  if (cfg == 99999) { g_phase_delay = -1; return ZK_OK; }               // back to the built-in policy
-  if (cfg >= 100 && cfg <= 116) { g_force_splits = cfg - 100; return ZK_OK; }   // 100 = heuristic, 101 = off
-  if (cfg < -1 || cfg > 4) return ZK_EINVAL;
-  g_force_tile = cfg;
-  return ZK_OK;
-}
-
 extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                             int64_t ldb, int64_t ldc, int transA, int transB, int epilogue, const void* bias,
                             const void* residual, int64_t ldr, void* aux_out, const void* aux_in, int64_t ldaux,
                             float alpha, const float* alpha_dev, int accumulate, void* workspace,
                             int64_t workspace_bytes, hipStream_t stream) {
+  return zk_gemm_bf16_plan(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, epilogue, bias, residual, ldr, aux_out,
+                           aux_in, ldaux, alpha, alpha_dev, accumulate, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                 int64_t ldb, int64_t ldc, int transA, int transB, int epilogue, const void* bias,
+                                 const void* residual, int64_t ldr, void* aux_out, const void* aux_in, int64_t ldaux,
+                                 float alpha, const float* alpha_dev, int accumulate, void* workspace,
+                                 int64_t workspace_bytes, const zk_gemm_plan_t* plan, hipStream_t stream) {
+  Plan P;
+  if (plan) {
+    if (plan->tile < -1 || plan->tile > 4 || plan->splits < 0 || plan->splits > 16 || plan->band < 0 || plan->band > 16)
+      return ZK_EINVAL;
+    P.tile = plan->tile; P.splits = plan->splits;
+    if (plan->stage_mode >= 0) P.stage_mode = plan->stage_mode != 0;
+    if (plan->ring >= 0) P.ring = plan->ring != 0;
+    if (plan->lean >= 0) P.lean = plan->lean != 0;
+    if (plan->pring >= 0) P.pring = plan->pring != 0;
+    P.band = plan->band; P.phase_delay = plan->phase_delay;
+#ifdef ZK_ABLATION
+    P.ring_mode = plan->ablation;
+#else
+    if (plan->ablation) return ZK_EINVAL;       // wrong-result timing modes exist in ZK_ABLATION builds only
+#endif
+  }
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ZK_EINVAL;
   if ((N & 7) || (ldc & 7)) return ZK_EINVAL;   // the epilogue moves 8 consecutive n (16 bytes) per lane
   if ((!transA || !transB) && (K & 7)) return ZK_EINVAL;  // k-contiguous operands are read in 8-element chunks
@@ -1131,10 +1143,10 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
   g.splits = 1; g.kchunk = (int)((K + BK - 1) / BK * BK); g.slab = nullptr;
   // split-K for small outputs with a long contraction (wgrad, lm_head dgrad): fill the 256 CUs
   const bool plain = epilogue == ZK_EPI_NONE && !bias && !residual && !aux_out;
-  if (plain && workspace && g_force_splits != 1) {
+  if (plain && workspace && P.splits != 1) {
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    int64_t sp = g_force_splits > 1 ? g_force_splits : (tiles <= 300 && K >= 2048 ? 1024 / tiles : 1);
-    if (g_force_splits <= 1 && tiles > 300 && tiles <= 1024 && K >= 4096) {
+    int64_t sp = P.splits > 1 ? P.splits : (tiles <= 300 && K >= 2048 ? 1024 / tiles : 1);
+    if (P.splits <= 1 && tiles > 300 && tiles <= 1024 && K >= 4096) {
       // mid-size outputs with a long contraction (the adapter's 3072 x 3072 weight gradient: 576 tiles are
       // 1.125 rounds of the 512 block slots): the smallest split that fills its last round, if the
       // unsplit grid wastes more than a tenth over it
@@ -1153,7 +1165,7 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
   }
   if (g.splits > 1) {
     g_last_plan = 4000 + g.splits;
-    launch_cfg<128, 128, 2, 2>(g, transA, transB, stream);
+    launch_cfg<128, 128, 2, 2>(g, transA, transB, stream, P);
     int64_t nb = (M * (N / 4) + 255) / 256;
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)nb), dim3(256), 0, stream, g.slab, g.C, g.M, g.N, g.ldc,
@@ -1161,40 +1173,40 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
     ZK_CHECK_LAUNCH();
     return ZK_OK;
   }
-  const int tile = choose_tile(M, N, transA, transB, epilogue == ZK_EPI_SWIGLU);
+  const int tile = choose_tile(M, N, transA, transB, epilogue == ZK_EPI_SWIGLU, P);
   g_last_plan = tile * 100;            // plain two-stage kernel unless a ring variant takes over below
   switch (tile) {
-    case 3: launch_cfg<128, 96, 2, 2>(g, transA, transB, stream); break;
+    case 3: launch_cfg<128, 96, 2, 2>(g, transA, transB, stream, P); break;
     case 4:
     case 2: {
-      if (!transA && !transB && g_ring) {
+      if (!transA && !transB && P.ring) {
         GemmArgs gr = g;
         const int bm = tile == 4 ? 384 : 256, bn = tile == 4 ? 192 : 256;
         gr.tiles_m = (g.M + bm - 1) / bm; gr.tiles_n = (g.N + bn - 1) / bn;
         const dim3 rg(gr.tiles_m * gr.tiles_n);
-        const bool lean = g.M % bm == 0 && g.N % bn == 0 && g.K % BK == 0 && g_lean;
+        const bool lean = g.M % bm == 0 && g.N % bn == 0 && g.K % BK == 0 && P.lean;
         // persistent ring: needs >= 4 K-tiles per tile and whole-matrix 32-bit byte offsets; the
         // erf-GELU epilogues (adapter only) stay on the one-tile-per-workgroup kernel
-        const int pclass = g_ring_mode == 3 ? 3
+        const int pclass = P.ring_mode == 3 ? 3
                            : epilogue == ZK_EPI_NONE ? 0
                            : (epilogue == ZK_EPI_QUICK_GELU || epilogue == ZK_EPI_MUL_DQUICK_GELU) ? 1
                            : (epilogue == ZK_EPI_SWIGLU || epilogue == ZK_EPI_SWIGLU_BWD) ? 2 : -1;
-        if (g_pring && pclass >= 0 && (g.K + BK - 1) / BK >= 4 && (M + 64) * lda * 2 < 0x7FFFFFF0LL &&
-            (N + 64) * ldb * 2 < 0x7FFFFFF0LL && (g_ring_mode == 0 || g_ring_mode == 3)) {
+        if (P.pring && pclass >= 0 && (g.K + BK - 1) / BK >= 4 && (M + 64) * lda * 2 < 0x7FFFFFF0LL &&
+            (N + 64) * ldb * 2 < 0x7FFFFFF0LL && (P.ring_mode == 0 || P.ring_mode == 3)) {
           const int ncu = num_cus();
           const int ntl = gr.tiles_m * gr.tiles_n;
           const dim3 pg(ntl < ncu ? ntl : ncu);
           g_last_plan = 3000 + tile * 100 + (lean ? 10 : 0) + pclass;
           // an XCD holds 32 consecutive tiles of the order = band x (32 / band): its L2 then streams
           // band * BM rows of A and (32 / band) * BN rows of B per K-tile; 384x192 tiles want 4 x 8
-          gr.band = g_band > 0 ? g_band : (tile == 4 ? 4 : 8);
+          gr.band = P.band > 0 ? P.band : (tile == 4 ? 4 : 8);
           // Start stagger.  Identical workgroups reach their epilogues together, and 256 CUs storing
           // 128-256 KiB each within the same few microseconds run into the fabric's write rate (the
           // stores block at issue, the matrix pipes idle).  Starting the 32 workgroups of an XCD in 4
           // phases 3 us apart spreads every later tile boundary; measured (tools/bench_phase.py): fused
           // gate|up 589 -> 501 us, fused down-dgrad 316 -> 294, lm_head 710 -> 684, C2 fc1 437 -> 412;
           // with fewer than 3 tiles per workgroup the 9 us tail is not earned back.
-          gr.phase_delay = g_phase_delay >= 0 ? g_phase_delay : (ntl >= 3 * ncu ? 300 : 0);
+          gr.phase_delay = P.phase_delay >= 0 ? P.phase_delay : (ntl >= 3 * ncu ? 300 : 0);
 #define ZK_PRING(EPI_) \
   do { \
     if (tile == 4 && lean) hipLaunchKernelGGL((gemm_pring_kernel<384, 192, 4, 2, 192, 6, true, EPI_>), pg, dim3(512), 0, stream, gr); \
@@ -1217,30 +1229,30 @@ extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, in
     else if (lean) hipLaunchKernelGGL((gemm_ringx_kernel<256, 256, 2, 4, 256, 5, MODE_, true>), rg, dim3(512), 0, stream, gr); \
     else hipLaunchKernelGGL((gemm_ringx_kernel<256, 256, 2, 4, 256, 5, MODE_, false>), rg, dim3(512), 0, stream, gr); \
   } while (0)
-        if (g_ring_mode == 1) ZK_RINGX(1);
-        else if (g_ring_mode == 2) ZK_RINGX(2);
-        else if (g_ring_mode == 3) ZK_RINGX(3);
+        if (P.ring_mode == 1) ZK_RINGX(1);
+        else if (P.ring_mode == 2) ZK_RINGX(2);
+        else if (P.ring_mode == 3) ZK_RINGX(3);
         else ZK_RINGX(0);
 #undef ZK_RINGX
       } else {
-        launch_cfg<256, 256, 2, 4>(g, transA, transB, stream);
+        launch_cfg<256, 256, 2, 4>(g, transA, transB, stream, P);
       }
       break;
     }
     case 1:
-      if (!transA && !transB && g_ring) {
+      if (!transA && !transB && P.ring) {
         GemmArgs gr = g;
         gr.tiles_m = (g.M + 255) / 256; gr.tiles_n = (g.N + 127) / 128;
         const dim3 rg(gr.tiles_m * gr.tiles_n);
         g_last_plan = 1000 + tile * 100;
-        if (g_ring_mode == 1) hipLaunchKernelGGL((gemm_ring_kernel<256, 128, 4, 2, 3, 1>), rg, dim3(512), 0, stream, gr);
-        else if (g_ring_mode == 2) hipLaunchKernelGGL((gemm_ring_kernel<256, 128, 4, 2, 3, 2>), rg, dim3(512), 0, stream, gr);
+        if (P.ring_mode == 1) hipLaunchKernelGGL((gemm_ring_kernel<256, 128, 4, 2, 3, 1>), rg, dim3(512), 0, stream, gr);
+        else if (P.ring_mode == 2) hipLaunchKernelGGL((gemm_ring_kernel<256, 128, 4, 2, 3, 2>), rg, dim3(512), 0, stream, gr);
         else hipLaunchKernelGGL((gemm_ring_kernel<256, 128, 4, 2, 3>), rg, dim3(512), 0, stream, gr);
       } else {
-        launch_cfg<256, 128, 4, 2>(g, transA, transB, stream);
+        launch_cfg<256, 128, 4, 2>(g, transA, transB, stream, P);
       }
       break;
-    default: launch_cfg<128, 128, 2, 2>(g, transA, transB, stream); break;
+    default: launch_cfg<128, 128, 2, 2>(g, transA, transB, stream, P); break;
   }
   ZK_CHECK_LAUNCH();
   return ZK_OK;

@@ -11,7 +11,9 @@ from typing import Optional
 
 import torch
 
-from ._lib import check, lib
+import ctypes
+
+from ._lib import GemmPlan, check, lib
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_MUL_DQUICK_GELU, EPI_MUL_DGELU_ERF = 0, 1, 2, 3, 4
 EPI_SWIGLU, EPI_SWIGLU_BWD = 5, 6
@@ -52,11 +54,25 @@ WORKSPACE_BYTES = 160 << 20
 
 
 def _workspace(device) -> torch.Tensor:
-    """Per-device fp32 scratch for split-K GEMMs, allocated once (the C ABI never allocates)."""
-    ws = _WORKSPACE.get(device)
+    """fp32 scratch for split-K GEMMs, one per (device, stream) — two streams that each run a split-K product
+    must not share partial slabs — allocated on first use (the C ABI never allocates)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACE.get(key)
     if ws is None:
-        ws = _WORKSPACE[device] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+        ws = _WORKSPACE[key] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
     return ws
+
+
+# Kernel plan forced by tests / tools (None = the library's cost model).  This is state of the PYTHON harness,
+# passed per call through zk_gemm_bf16_plan: libzero_hip.so itself holds no mutable tuning state.
+_PLAN = None
+
+
+def _gemm_call(*args):
+    """args = the zk_gemm_bf16 argument list without the trailing stream."""
+    if _PLAN is None:
+        return lib.zk_gemm_bf16(*args, _stream())
+    return lib.zk_gemm_bf16_plan(*args, ctypes.addressof(_PLAN), _stream())
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
@@ -103,10 +119,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
         rc = lib.zk_gemv_bf16(_p(a), _p(b), _p(out), M, N, K, _ld(a), _ld(b), _ld(out), _p(residual), ldr, _stream())
         check(rc, f"zk_gemv_bf16 M={M} N={N} K={K}")
         return out
-    rc = lib.zk_gemm_bf16(_p(a), _p(b), _p(out), M, N, K, _ld(a), _ld(b), _ld(out),
-                          int(trans_a), int(trans_b), epilogue, _p(bias), _p(residual), ldr, _p(aux_out),
-                          _p(aux_in), ldaux, float(alpha), _p(alpha_dev), int(accumulate),
-                          _workspace(a.device).data_ptr(), WORKSPACE_BYTES, _stream())
+    rc = _gemm_call(_p(a), _p(b), _p(out), M, N, K, _ld(a), _ld(b), _ld(out),
+                    int(trans_a), int(trans_b), epilogue, _p(bias), _p(residual), ldr, _p(aux_out),
+                    _p(aux_in), ldaux, float(alpha), _p(alpha_dev), int(accumulate),
+                    _workspace(a.device).data_ptr(), WORKSPACE_BYTES)
     check(rc, f"zk_gemm_bf16 M={M} N={N} K={K} tA={trans_a} tB={trans_b}")
     return out
 
@@ -146,9 +162,9 @@ def gemm_swiglu(x: torch.Tensor, wgu_i: torch.Tensor):
         raise ValueError("gemm_swiglu: shapes")
     gu = torch.empty((M, N), dtype=BF16, device=x.device)
     h = torch.empty((M, N // 2), dtype=BF16, device=x.device)
-    rc = lib.zk_gemm_bf16(_p(x), _p(wgu_i), _p(gu), M, N, K, _ld(x), _ld(wgu_i), _ld(gu), 0, 0,
-                          EPI_SWIGLU, None, None, 0, _p(h), None, _ld(h), 1.0, None, 0,
-                          _workspace(x.device).data_ptr(), WORKSPACE_BYTES, _stream())
+    rc = _gemm_call(_p(x), _p(wgu_i), _p(gu), M, N, K, _ld(x), _ld(wgu_i), _ld(gu), 0, 0,
+                    EPI_SWIGLU, None, None, 0, _p(h), None, _ld(h), 1.0, None, 0,
+                    _workspace(x.device).data_ptr(), WORKSPACE_BYTES)
     check(rc, f"zk_gemm_bf16(SWIGLU) M={M} N={N} K={K}")
     return gu, h
 
@@ -162,9 +178,9 @@ def gemm_swiglu_bwd(dy: torch.Tensor, w_down_t: torch.Tensor, gu_i: torch.Tensor
     if w_down_t.shape[1] != K or gu_i.shape != (M, 2 * F) or F % 32:
         raise ValueError("gemm_swiglu_bwd: shapes")
     dgu = torch.empty((M, 2 * F), dtype=BF16, device=dy.device)
-    rc = lib.zk_gemm_bf16(_p(dy), _p(w_down_t), _p(dgu), M, F, K, dy.stride(0), w_down_t.stride(0), dgu.stride(0), 0, 0,
-                          EPI_SWIGLU_BWD, None, None, 0, None, _p(gu_i), gu_i.stride(0), 1.0, None, 0,
-                          _workspace(dy.device).data_ptr(), WORKSPACE_BYTES, _stream())
+    rc = _gemm_call(_p(dy), _p(w_down_t), _p(dgu), M, F, K, dy.stride(0), w_down_t.stride(0), dgu.stride(0), 0, 0,
+                    EPI_SWIGLU_BWD, None, None, 0, None, _p(gu_i), gu_i.stride(0), 1.0, None, 0,
+                    _workspace(dy.device).data_ptr(), WORKSPACE_BYTES)
     check(rc, f"zk_gemm_bf16(SWIGLU_BWD) M={M} N={F} K={K}")
     return dgu
 
@@ -423,5 +439,38 @@ def f32_to_bf16_multi_(pairs, scale: float = 1.0):
 
 
 def set_gemm_tile(cfg: int = -1):
-    """Tuning hook: force the GEMM block tile (-1 cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256)."""
-    check(lib.zk_gemm_set_tile(int(cfg)), "zk_gemm_set_tile")
+    """Test / tool hook: edit the per-call kernel plan that ops.gemm passes to zk_gemm_bf16_plan (the numeric
+    codes are kept from the round-1 tools).  -1 / 0..4 tile (cost model, 128x128, 256x128, 256x256, 128x96,
+    384x192); 10 / 11 staging mode; 20 / 21 256x128 ring off / on; 30..33 ablation mode (needs a -DZK_ABLATION
+    build); 40 / 41 lean addressing; 50 / 51 persistent ring off / on; 60 + b band; 100 split-K heuristic,
+    101 no split-K, 102..116 forced splits; 100000 + t start stagger, 99999 built-in stagger.  When every field
+    is back at its default the plan is dropped and the plain zk_gemm_bf16 entry is called again."""
+    global _PLAN
+    cfg = int(cfg)
+    pl = _PLAN if _PLAN is not None else GemmPlan.default()
+    if cfg in (10, 11):
+        pl.stage_mode = cfg - 10
+    elif cfg in (20, 21):
+        pl.ring = cfg - 20
+    elif 30 <= cfg <= 33:
+        pl.ablation = cfg - 30
+    elif cfg in (40, 41):
+        pl.lean = cfg - 40
+    elif cfg in (50, 51):
+        pl.pring = cfg - 50
+    elif 60 <= cfg <= 76:
+        pl.band = cfg - 60
+    elif cfg >= 100000:
+        pl.phase_delay = cfg - 100000
+    elif cfg == 99999:
+        pl.phase_delay = -1
+    elif 100 <= cfg <= 116:
+        pl.splits = cfg - 100
+    elif -1 <= cfg <= 4:
+        pl.tile = cfg
+    else:
+        raise ValueError(f"set_gemm_tile: unknown code {cfg}")
+    d = GemmPlan.default()
+    same = all(getattr(pl, n) == getattr(d, n) or (n in ("stage_mode", "ring", "lean", "pring") and getattr(pl, n) == 1)
+               for n, _ in GemmPlan._fields_)
+    _PLAN = None if same else pl
