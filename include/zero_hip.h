@@ -13,7 +13,7 @@
  *   - every call is asynchronous on `stream`, allocates nothing, never synchronises,
  *     never changes the current device; the caller owns every buffer;
  *   - returns 0 on success, a negative errno-style code otherwise
- *     (-22 invalid argument / unsupported shape, -5 launch failure);
+ *     (-22 invalid argument / unsupported shape, -5 launch failure, -7 beyond a stated size limit);
  *   - 16-byte aligned base pointers; feature dimensions are multiples of 8.
  */
 #ifndef ZERO_HIP_H_
@@ -155,6 +155,21 @@ int zk_attn_decode_fused(const void* qkv, const float* cos_row, const float* sin
                          void* v_cache, void* out, float* ws, int64_t ws_floats, int64_t B, int64_t Hq,
                          int64_t Hkv, int64_t head_dim, int64_t ldqkv, int64_t ldo, int64_t cache_rows,
                          int64_t pos, float scale, hipStream_t stream);
+
+/* zk_attn_decode_fused for callers that cannot allocate or carry a workspace — code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  NO counterpart in the reference.  Same arguments minus
+ * ws / ws_floats, same kernels, same results bit for bit; the fp32 partials live in a device array inside the
+ * library's code object (ZK_ATTN_DECODE_STATIC_FLOATS floats = 8 MiB, held on every GPU the library runs on until
+ * the process ends).  Calls hipMalloc / hipFree / no allocating routine, ever; the first call on each device looks
+ * the array's address up (hipGetSymbolAddress; make that first call outside a capture).
+ * Limit: B * Hq * (pos / 64 + 1) * (head_dim + 2) <= ZK_ATTN_DECODE_STATIC_FLOATS, otherwise -7 (E2BIG) and nothing
+ * is launched (e.g. 8 q heads x hd 128, B = 1: 129,000 cached keys; 32 heads, B = 4: 8,064).
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams) race. */
+#define ZK_ATTN_DECODE_STATIC_FLOATS (2 * 1024 * 1024)
+int zk_attn_decode_fused_static(const void* qkv, const float* cos_row, const float* sin_row, void* k_cache,
+                                void* v_cache, void* out, int64_t B, int64_t Hq, int64_t Hkv, int64_t head_dim,
+                                int64_t ldqkv, int64_t ldo, int64_t cache_rows, int64_t pos, float scale,
+                                hipStream_t stream);
 
 /* One Llama decoder layer on a single-token decoding step, enqueued natively in two halves so a
  * tensor-parallel host can all-reduce the partial sums between them (tf:llama:295-324 with a KV cache;

@@ -31,6 +31,7 @@ SIGNATURES = {
     "zk_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "zk_attn_decode": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P],
     "zk_attn_decode_fused": [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P],
+    "zk_attn_decode_fused_static": [_P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P],
     "zk_llama_decode_attn": [_P, _P, _P, _I, _P],
     "zk_llama_decode_mlp": [_P, _P, _P, _I, _P],
     "zk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _L, _F, _P],

@@ -21,6 +21,7 @@
 // next tile's loads in flight during the MFMAs; one barrier per tile.
 // dQ is produced by its own pass (recomputing S and dP) instead of fp32 atomics: it is
 // deterministic, and attention is < 3 % of the step's FLOPs.
+#include <atomic>
 #include "common.h"
 #include "../../include/zero_hip.h"
 
@@ -847,10 +848,10 @@ __global__ __launch_bounds__(HD) void attn_decode_merge_kernel(const float* ws, 
 
 }  // namespace
 
-extern "C" int zk_attn_decode_fused(const void* qkv, const float* cos_row, const float* sin_row, void* k_cache,
-                                    void* v_cache, void* out, float* ws, int64_t ws_floats, int64_t B, int64_t Hq,
-                                    int64_t Hkv, int64_t head_dim, int64_t ldqkv, int64_t ldo, int64_t cache_rows,
-                                    int64_t pos, float scale, hipStream_t stream) {
+namespace {
+int decode_fused_launch(const void* qkv, const float* cos_row, const float* sin_row, void* k_cache, void* v_cache,
+                        void* out, float* ws, int64_t ws_floats, int64_t B, int64_t Hq, int64_t Hkv, int64_t head_dim,
+                        int64_t ldqkv, int64_t ldo, int64_t cache_rows, int64_t pos, float scale, hipStream_t stream) {
   if (!qkv || !cos_row || !sin_row || !k_cache || !v_cache || !out || !ws) return ZK_EINVAL;
   if (B <= 0 || B > 65535 || Hq <= 0 || Hkv <= 0 || Hkv > 65535 || Hq % Hkv || Hq / Hkv > 16) return ZK_EINVAL;
   if ((head_dim != 64 && head_dim != 128) || pos < 0 || pos >= cache_rows || (ldqkv & 7)) return ZK_EINVAL;
@@ -878,6 +879,60 @@ extern "C" int zk_attn_decode_fused(const void* qkv, const float* cos_row, const
   }
   ZK_CHECK_LAUNCH();
   return ZK_OK;
+}
+}  // namespace
+
+extern "C" int zk_attn_decode_fused(const void* qkv, const float* cos_row, const float* sin_row, void* k_cache,
+                                    void* v_cache, void* out, float* ws, int64_t ws_floats, int64_t B, int64_t Hq,
+                                    int64_t Hkv, int64_t head_dim, int64_t ldqkv, int64_t ldo, int64_t cache_rows,
+                                    int64_t pos, float scale, hipStream_t stream) {
+  return decode_fused_launch(qkv, cos_row, sin_row, k_cache, v_cache, out, ws, ws_floats, B, Hq, Hkv, head_dim, ldqkv,
+                             ldo, cache_rows, pos, scale, stream);
+}
+
+// ---- the same step for callers that cannot allocate (HIP graph capture, serving loops): the fp32 partials
+// (chunk max, chunk sum, un-normalised output per 64-key chunk and q head) live in a device array of the code
+// object instead of a caller workspace.  `scratch` is a HOST-SIDE STAND-IN here, not a device address: host code
+// only ever uses the per-device pointer hipGetSymbolAddress returned (each GPU holds its own copy of the array at
+// its own address).  Nothing in it has to start at zero: the partial pass writes every word the merge pass reads.
+// Calls that overlap on one GPU (two streams) race on the array.
+static __device__ __align__(256) float scratch[ZK_ATTN_DECODE_STATIC_FLOATS];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::atomic<float*> g_scratch_ptr[kMaxDevices];     // per device, set once by the first call on that device
+
+int scratch_for_current_device(float** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return ZK_EINVAL;
+  float* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!p) {
+    void* sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)) != hipSuccess || !sym) return ZK_ELAUNCH;
+    p = static_cast<float*>(sym);
+    g_scratch_ptr[dev].store(p, std::memory_order_release);   // racing first calls look up the same address
+  }
+  *out = p;
+  return ZK_OK;
+}
+}  // namespace
+
+extern "C" int zk_attn_decode_fused_static(const void* qkv, const float* cos_row, const float* sin_row, void* k_cache,
+                                           void* v_cache, void* out, int64_t B, int64_t Hq, int64_t Hkv,
+                                           int64_t head_dim, int64_t ldqkv, int64_t ldo, int64_t cache_rows,
+                                           int64_t pos, float scale, hipStream_t stream) {
+  if (B <= 0 || Hq <= 0 || pos < 0 || (head_dim != 64 && head_dim != 128)) return ZK_EINVAL;
+  const int64_t nchunks = pos / 64 + 1;
+  // reject what does not fit BEFORE touching the device (no silent truncation; -7 = argument list too big)
+  if (B > ZK_ATTN_DECODE_STATIC_FLOATS || Hq > ZK_ATTN_DECODE_STATIC_FLOATS ||
+      B * Hq > ZK_ATTN_DECODE_STATIC_FLOATS / (head_dim + 2) ||
+      nchunks > ZK_ATTN_DECODE_STATIC_FLOATS / ((head_dim + 2) * B * Hq))
+    return ZK_E2BIG;
+  float* ws = nullptr;
+  const int rc = scratch_for_current_device(&ws);
+  if (rc != ZK_OK) return rc;
+  return decode_fused_launch(qkv, cos_row, sin_row, k_cache, v_cache, out, ws, ZK_ATTN_DECODE_STATIC_FLOATS, B, Hq, Hkv,
+                             head_dim, ldqkv, ldo, cache_rows, pos, scale, stream);
 }
 
 extern "C" int zk_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out, const int* lens,

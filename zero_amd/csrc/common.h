@@ -17,6 +17,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define ZK_OK 0
 #define ZK_EINVAL (-22)
 #define ZK_ELAUNCH (-5)
+#define ZK_E2BIG (-7)
 
 #define ZK_CHECK_LAUNCH()                                   \
   do {                                                      \
