@@ -295,9 +295,9 @@ def main():
         _bw("zk_rmsnorm_fwd", lambda a: a[4] * a[5] * 4)
         _bw("zk_rmsnorm_bwd", lambda a: a[6] * a[7] * (8 if a[4] else 6))
         _bw("zk_layernorm_fwd", lambda a: a[6] * a[7] * 4)
-        _bw("zk_layernorm_bwd", lambda a: a[9] * a[10] * ((6 if a[6] else 4) + (2 if a[5] else 0)))
+        _bw("zk_layernorm_bwd", lambda a: a[10] * a[11] * ((6 if a[6] else 4) + (2 if a[5] else 0)))
         _bw("zk_rope", lambda a: a[3] * a[5] * a[6] * 4)
-        _bw("zk_cross_entropy", lambda a: a[4] * a[5] * (4 if a[3] else 2))
+        _bw("zk_cross_entropy", lambda a: a[5] * a[6] * (4 if a[4] else 2))
         _bw("zk_adamw_step", lambda a: a[4] * 22)
 
         real_lib = ops.lib

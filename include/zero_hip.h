@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ZK_ABI_VERSION 2
+#define ZK_ABI_VERSION 3
 int zk_abi_version(void);
 
 /* ---- GEMM -------------------------------------------------------------------------
@@ -201,27 +201,31 @@ int zk_llama_decode_mlp(const zk_decode_layer_t* L, const void* xa, void* out, i
 /* ---- LayerNorm (tf:clip:358-360,370,379,605,642; ref:adapter.py:94) ------------------
  * y = (x - mean) * rstd * gamma + beta over the last dim D (<= 8192, multiple of 8),
  * fp32 statistics.  mean/rstd [rows] fp32 are optional outputs of fwd (needed by bwd).
- * bwd: dx = dres + LN'(dy); dgamma/dbeta are ACCUMULATED into fp32 [D] buffers (may be
- * null when the affine parameters are frozen).
+ * bwd: dx = dres + LN'(dy).  The affine gradients come out as PARTIAL sums: dgamma / dbeta are fp32
+ * [nparts][D] buffers that the call OVERWRITES (part p = the rows workgroup p walked; 1 <= nparts <=
+ * ZK_NORM_MAX_PARTS, about rows / 16 is a good choice); the caller adds the parts in index order
+ * (zk_f32_to_bf16_multi does while converting).  No atomics: results are bit-reproducible.  Both may be
+ * null when the affine parameters are frozen (nparts is then ignored).
  */
+#define ZK_NORM_MAX_PARTS 512
 int zk_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean,
                      float* rstd, int64_t rows, int64_t D, float eps, hipStream_t stream);
 int zk_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean,
                      const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                     int64_t rows, int64_t D, hipStream_t stream);
+                     int64_t nparts, int64_t rows, int64_t D, hipStream_t stream);
 
 /* ---- RMSNorm (tf:llama:62-67) ----------------------------------------------------------
  * y = w * bf16(x * rsqrt(mean(x^2) + eps)); bwd gives dx = dres + RMS'(dy); the weight gradient
- * dweight[c] += sum_rows dy[r][c] * bf16(x[r][c] * rstd[r]) (fp32 [D], accumulated into) is a
- * separate call, needed only where decoder layers train (stage "pretrain": the translator layer,
- * ref:configs/zero/train_llama.py:281-307).
+ * sum_rows dy[r][c] * bf16(x[r][c] * rstd[r]) is a separate call, needed only where decoder layers train
+ * (stage "pretrain": the translator layer, ref:configs/zero/train_llama.py:281-307); like the LayerNorm
+ * affine gradients it is written as fp32 partial sums dweight[nparts][D] (overwritten, no atomics).
  */
 int zk_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t D,
                    float eps, hipStream_t stream);
 int zk_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd,
                    const void* dres, void* dx, int64_t rows, int64_t D, hipStream_t stream);
 int zk_rmsnorm_dweight(const void* dy, const void* x, const float* rstd, float* dweight,
-                       int64_t rows, int64_t D, hipStream_t stream);
+                       int64_t nparts, int64_t rows, int64_t D, hipStream_t stream);
 
 /* ---- RoPE (tf:llama:130-160; cos/sin table tf:llama:113-127) ---------------------------
  * In place on `heads` consecutive heads of width head_dim inside rows of stride ld:
@@ -240,9 +244,10 @@ int zk_swiglu_bwd(const void* dh, const void* gu, void* dgu, int64_t rows, int64
                   hipStream_t stream);
 
 /* ---- column sum: bias gradients (autograd of the biased Linears) -----------------------
- * out[n] += sum_m dy[m][n], fp32 accumulation buffer.
+ * out[p][n] = sum over the rows of part p of dy[m][n]: fp32 [nparts][N], OVERWRITTEN (rows are dealt to the
+ * parts in groups of 8; no atomics, bit-reproducible); the caller adds the parts in index order.
  */
-int zk_colsum(const void* dy, float* out, int64_t rows, int64_t N, int64_t ld,
+int zk_colsum(const void* dy, float* out, int64_t rows, int64_t N, int64_t ld, int64_t nparts,
               hipStream_t stream);
 
 /* ---- activation backward (autograd of tf:activations.py:117-123 / nn.GELU) -------------
@@ -273,18 +278,23 @@ int zk_gather_rows(const void* table0, const void* table1, const int32_t* codes,
  * For each row: fp32 log-softmax over V, loss = -logp[target] unless target == -100.
  * Adds the row losses into loss_sum[0] (fp32) and the number of non-ignored rows into
  * loss_sum[1]; when dlogits != null writes (softmax - onehot) (0 for ignored rows) as bf16
- * (may alias logits).
+ * (may alias logits).  row_loss (optional fp32 [rows] scratch): when given, every row's loss is stored there
+ * and a second one-block kernel adds them in index order (bit-reproducible loss); when null the rows add
+ * themselves with fp32 atomics (order-dependent last bits).
  */
-int zk_cross_entropy(const void* logits, const int32_t* targets, float* loss_sum, void* dlogits,
-                     int64_t rows, int64_t V, int64_t ld, hipStream_t stream);
+int zk_cross_entropy(const void* logits, const int32_t* targets, float* loss_sum, float* row_loss,
+                     void* dlogits, int64_t rows, int64_t V, int64_t ld, hipStream_t stream);
 
 /* ---- optimizer tail (ref:train.py:570-580: clip_grad_norm_ + AdamW.step) -----------------
- * sumsq: out[0] += sum(g^2) over a flat bf16 buffer.  adamw_step: flat bf16 params/grads,
+ * sumsq: out[0] += sum(g^2) over a flat bf16 buffer; parts (optional fp32 [ZK_SUMSQ_PARTS] scratch): per-block
+ * sums stored there and added in index order by a second one-block kernel (bit-reproducible clip coefficient),
+ * otherwise fp32 atomics.  adamw_step: flat bf16 params/grads,
  * fp32 moments; the clip coefficient min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) is
  * computed on the device from sumsq (max_norm <= 0: no clipping); grad_scale multiplies
  * every gradient first (1/world_size for the DDP average).
  */
-int zk_sumsq(const void* g, float* out, int64_t n, float scale, hipStream_t stream);
+#define ZK_SUMSQ_PARTS 1024
+int zk_sumsq(const void* g, float* out, float* parts, int64_t n, float scale, hipStream_t stream);
 int zk_adamw_step(void* p, const void* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int64_t step, float max_norm,
                   const float* sumsq, float grad_scale, hipStream_t stream);
@@ -295,10 +305,12 @@ int zk_adamw_step(void* p, const void* g, float* m, float* v, int64_t n, float l
 int zk_f32_to_bf16(const float* src, void* dst, int64_t n, float scale, int accumulate,
                    hipStream_t stream);
 /* The same for up to 16 independent segments in one launch (host arrays of `count` entries): the
- * bias / norm-affine gradients of one layer, each converted from its fp32 accumulator into its own
- * slot of the flat gradient buffer. */
+ * bias / norm-affine gradients of one layer, each converted from its fp32 partial sums (nparts[i] rows of n[i]
+ * values, part_stride[i] elements apart, added in part order; nparts null = 1 each, part_stride null = n[i])
+ * into its own slot of the flat gradient buffer. */
 int zk_f32_to_bf16_multi(const float* const* src, void* const* dst, const int64_t* n,
-                         const int* accumulate, int count, float scale, hipStream_t stream);
+                         const int* accumulate, const int* nparts, const int64_t* part_stride, int count,
+                         float scale, hipStream_t stream);
 
 /* ---- image data path -------------------------------------------------
  * What ref:loader.py:171-195 does per sample with PIL + CLIPImageProcessor (PIL backend):

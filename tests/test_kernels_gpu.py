@@ -280,16 +280,20 @@ def test_gemm_rejects_bad_shapes():
 
 
 def test_rmsnorm_dweight():
-    """dW of LlamaRMSNorm (tf:llama:62-67: w * bf16(x * rstd)) against autograd, accumulate semantics."""
-    for rows, D in ((700, 256), (1536, 3072), (37, 4096)):
+    """dW of LlamaRMSNorm (tf:llama:62-67: w * bf16(x * rstd)) against autograd: partial sums [nparts, D],
+    overwritten (stale contents must not leak), bit-reproducible."""
+    for rows, D, nparts in ((700, 256, 44), (1536, 3072, 96), (37, 4096, 1), (37, 4096, 7)):
         x, dy, w = rnd(rows, D, seed=71), rnd(rows, D, seed=72), rnd(D, seed=73)
         _, rstd = ops.rmsnorm_fwd(x, w, 1e-5)
-        acc = torch.full((D,), 0.5, dtype=torch.float32, device=DEV)
-        ops.rmsnorm_dweight_(dy, x, rstd, acc)
+        parts = torch.full((nparts, D), float("nan"), dtype=torch.float32, device=DEV)
+        ops.rmsnorm_dweight_(dy, x, rstd, parts)
         xf = x.float()
         xh = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).to(torch.bfloat16).float()
-        ref = (dy.float() * xh).sum(0) + 0.5
-        assert relerr(acc, ref) < 2e-3
+        ref = (dy.float() * xh).sum(0)
+        assert relerr(parts.sum(0), ref) < 2e-3
+        again = torch.zeros_like(parts)
+        ops.rmsnorm_dweight_(dy, x, rstd, again)
+        assert torch.equal(parts, again)
 
 
 # ------------------------------------------------------------------ attention
@@ -359,20 +363,33 @@ def test_layernorm_fwd(rows, D):
     assert relerr(mean, x.float().mean(-1)) < 1e-4 or (mean - x.float().mean(-1)).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("rows,D", [(577 * 2, 1024), (37, 256), (50, 3072)])
-def test_layernorm_bwd(rows, D):
+@pytest.mark.parametrize("rows,D,nparts", [(577 * 2, 1024, 73), (577 * 8, 1024, 289), (577 * 64, 1024, 512), (37, 256, 3),
+                                           (5, 1024, 1), (50, 3072, 4), (50, 3072, 13)])
+def test_layernorm_bwd(rows, D, nparts):
+    """dx and the affine gradients as partial sums [nparts, D] (overwritten: stale NaNs must not leak; the parts
+    added in order give the gradient; two runs are bit-identical — no atomics)."""
     x, g, b = rnd(rows, D, seed=44, scale=2.0), rnd(D, seed=45), rnd(D, seed=46)
     dy, dres = rnd(rows, D, seed=47), rnd(rows, D, seed=48)
     y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-5)
-    dgamma = torch.zeros(D, device=DEV); dbeta = torch.zeros(D, device=DEV)
+    dgamma = torch.full((nparts, D), float("nan"), device=DEV); dbeta = torch.full((nparts, D), float("nan"), device=DEV)
     dx = ops.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, dgamma=dgamma, dbeta=dbeta)
     xf = x.float().requires_grad_(True); gf = g.float().requires_grad_(True); bf = b.float().requires_grad_(True)
     F.layer_norm(xf, (D,), gf, bf, 1e-5).backward(dy.float())
     assert relerr(dx, xf.grad + dres.float()) < 8e-3
-    assert relerr(dgamma, gf.grad) < 1e-3
-    assert relerr(dbeta, bf.grad) < 1e-3
+    assert relerr(dgamma.sum(0), gf.grad) < 1e-3
+    assert relerr(dbeta.sum(0), bf.grad) < 1e-3
+    dg2, db2 = torch.zeros_like(dgamma), torch.zeros_like(dbeta)
+    dx_again = ops.layernorm_bwd(dy, x, g, mean, rstd, dres=dres, dgamma=dg2, dbeta=db2)
+    assert torch.equal(dx, dx_again) and torch.equal(dgamma, dg2) and torch.equal(dbeta, db2)
     dx2 = ops.layernorm_bwd(dy, x, g, mean, rstd)
     assert relerr(dx2, xf.grad) < 8e-3
+    # the ordered part sum + bf16 conversion the layer nodes use (zk_f32_to_bf16_multi)
+    slot = torch.zeros(D, dtype=torch.bfloat16, device=DEV)
+    ops.f32_to_bf16_multi_([(dgamma, slot, False)])
+    ref = dgamma[0].clone()
+    for p_ in range(1, nparts):
+        ref += dgamma[p_]
+    assert torch.equal(slot, ref.to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("rows,D", [(768 * 2, 3072), (37, 256), (9, 4096), (5, 8192)])
@@ -439,13 +456,23 @@ def test_act_bwd(kind):
 
 def test_colsum():
     dy = rnd(1154, 1032, seed=66)
-    out = torch.zeros(1032, device=DEV)
+    out = torch.full((18, 1032), float("nan"), device=DEV)          # partial sums, overwritten
     ops.colsum_(dy, out)
-    assert relerr(out, dy.float().sum(0)) < 1e-4
+    assert relerr(out.sum(0), dy.float().sum(0)) < 1e-4
+    again = torch.zeros_like(out)
+    ops.colsum_(dy, again)
+    assert torch.equal(out, again)                                  # no atomics: bit-reproducible
     view = dy[:, 8:520]
-    out2 = torch.ones(512, device=DEV)
+    out2 = torch.full((1, 512), float("nan"), device=DEV)
     ops.colsum_(view, out2)
-    assert relerr(out2, view.float().sum(0) + 1) < 1e-4
+    assert relerr(out2[0], view.float().sum(0)) < 1e-4
+    # column slices of one partial-sum slab go through the converter with their part stride (packed q|k|v biases)
+    slot = torch.ones(512, dtype=torch.bfloat16, device=DEV)
+    ops.f32_to_bf16_multi_([(out[:, 8:520], slot, True)])
+    ref = out[0, 8:520].clone()
+    for p_ in range(1, 18):
+        ref += out[p_, 8:520]
+    assert torch.equal(slot, (ref + 1).to(torch.bfloat16))
 
 
 # ------------------------------------------------------------------ patch embedding / gather / CE / optimizer

@@ -250,6 +250,49 @@ def test_drop_in_forward_list_contract():
         assert maxrel(a, b) <= 2e-2
 
 
+@pytest.mark.parametrize("shave,ignore_cls", [(2, False), (-1, True), (1, True)])
+def test_forward_shave_and_ignore_cls_branches(shave, ignore_cls):
+    """The two optional branches of Zero._forward (ref:models/adapter.py:85-92): take hidden_states[-n] instead of
+    the last hidden state, drop the CLS token — forward and the trainable gradients against the oracle."""
+    spec = GOLDEN_CONFIGS["tiny"]
+    enc, dec = spec["enc"], spec["dec"]
+    params = zo.make_params(enc, dec, spec["seed"], surrogate=True)
+    imgs, *_ = zo.synth_batch(enc, dec, **spec["batch"])
+    from tests.helpers import build_model, make_cfg
+    from zero_amd.configs.zero.train_llama import func_optim_filter
+    cfg = make_cfg(enc, dec, DEV, spec["ft_after"], spec["max_seq_len"])
+    cfg.encoder_shave_last_n_layers, cfg.ignore_encoder_cls_token = shave, ignore_cls
+    model = build_model(cfg, params)
+    func_optim_filter(cfg, model)
+    xs = [i.to(DEV).to(torch.bfloat16) for i in imgs[:2]]
+    out = model._forward(xs)
+    tok = enc.tokens - (1 if ignore_cls else 0)
+    assert [tuple(o.shape) for o in out] == [(2 + tok, dec.hidden)] * 2
+    g = torch.Generator(device="cpu").manual_seed(3)
+    R = torch.randn(2, 2 + tok, dec.hidden, generator=g)
+    (torch.stack(out).float() * R.to(DEV)).sum().backward()
+    p32 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = zo.zero_forward(p32, [x.float().cpu() for x in xs], enc, shave_last_n=shave, ignore_cls=ignore_cls)
+    (torch.stack(ref) * R).sum().backward()
+    for o, r in zip(out, ref):
+        assert maxrel(o, r) <= 2e-2
+    checked = 0
+    scale = max(v.grad.norm().item() / v.numel() ** 0.5 for v in p32.values() if v.grad is not None)
+    for n, p in model.named_parameters():
+        if not p.requires_grad or n.startswith("decoder."):
+            continue
+        r = p32[n].grad
+        if shave > 1 and f"layers.{enc.layers - 1}." in n:
+            # layers past the shaved hidden state get no gradient at all (neither here nor in the oracle)
+            assert p.grad is None or float(p.grad.float().abs().max()) == 0.0
+            assert r is None or float(r.abs().max()) == 0.0
+            continue
+        assert p.grad is not None and r is not None, n
+        assert grad_err(p.grad, r, scale * r.numel() ** 0.5) <= 3e-2, n
+        checked += 1
+    assert checked > 10
+
+
 def test_trainer_step_updates_and_accumulates():
     """Two micro-batches with gradient accumulation == the oracle's clip + AdamW on the summed
     gradients; slots are written by the wgrad kernels (no autograd .grad)."""

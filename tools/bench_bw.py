@@ -70,7 +70,7 @@ report("rmsnorm_bwd", f"[{R},{D}]", R * D * 6,
        timeit(lambda i: ops.rmsnorm_bwd(dys[i], xs[i], w, ys_rs[i][1]), len(xs)))
 report("rmsnorm_bwd + residual grad", f"[{R},{D}]", R * D * 8,
        timeit(lambda i: ops.rmsnorm_bwd(dys[i], xs[i], w, ys_rs[i][1], dres=ys_rs[i][0]), len(xs)))
-dw = torch.zeros(D, device=dev, dtype=torch.float32)
+dw = torch.zeros(ops.norm_parts(R), D, device=dev, dtype=torch.float32)
 report("rmsnorm_dweight", f"[{R},{D}]", R * D * 4,
        timeit(lambda i: ops.rmsnorm_dweight_(dys[i], xs[i], ys_rs[i][1], dw), len(xs)))
 del xs, ys_rs, dys
@@ -82,7 +82,7 @@ xs = pool(lambda: rnd(R, D), R * D * 4)
 st = [ops.layernorm_fwd(x, g, b, 1e-5) for x in xs]
 report("layernorm_fwd", f"[{R},{D}]", R * D * 4, timeit(lambda i: ops.layernorm_fwd(xs[i], g, b, 1e-5), len(xs)))
 dys = [rnd(R, D) for _ in xs]
-dg, db = torch.zeros(D, device=dev, dtype=torch.float32), torch.zeros(D, device=dev, dtype=torch.float32)
+dg, db = (torch.zeros(ops.norm_parts(R), D, device=dev, dtype=torch.float32) for _ in range(2))
 report("layernorm_bwd (+dgamma,dbeta)", f"[{R},{D}]", R * D * 8,
        timeit(lambda i: ops.layernorm_bwd(dys[i], xs[i], g, st[i][1], st[i][2], dres=st[i][0], dgamma=dg, dbeta=db),
               len(xs)))
@@ -111,7 +111,7 @@ R, F = 4616, 4096
 pre = pool(lambda: rnd(R, F), R * F * 6)
 dys = [rnd(R, F) for _ in pre]
 report("act_bwd quick_gelu", f"[{R},{F}]", R * F * 6, timeit(lambda i: ops.act_bwd(dys[i], pre[i], 1), len(pre)))
-ob = torch.zeros(F, device=dev, dtype=torch.float32)
+ob = torch.zeros(ops.colsum_parts(R), F, device=dev, dtype=torch.float32)
 report("colsum (bias gradient)", f"[{R},{F}]", R * F * 2, timeit(lambda i: ops.colsum_(dys[i], ob), len(pre)))
 del pre, dys
 

@@ -35,23 +35,23 @@ SIGNATURES = {
     "zk_llama_decode_attn": [_P, _P, _P, _I, _P],
     "zk_llama_decode_mlp": [_P, _P, _P, _I, _P],
     "zk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _L, _F, _P],
-    "zk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P],
+    "zk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P],
     "zk_rmsnorm_fwd": [_P, _P, _P, _P, _L, _L, _F, _P],
     "zk_rmsnorm_bwd": [_P, _P, _P, _P, _P, _P, _L, _L, _P],
-    "zk_rmsnorm_dweight": [_P, _P, _P, _P, _L, _L, _P],
+    "zk_rmsnorm_dweight": [_P, _P, _P, _P, _L, _L, _L, _P],
     "zk_rope": [_P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
     "zk_swiglu_fwd": [_P, _P, _L, _L, _P],
     "zk_swiglu_bwd": [_P, _P, _P, _L, _L, _P],
-    "zk_colsum": [_P, _P, _L, _L, _L, _P],
+    "zk_colsum": [_P, _P, _L, _L, _L, _L, _P],
     "zk_act_bwd": [_P, _P, _P, _L, _I, _P],
     "zk_patch_im2col": [_P, _P, _L, _L, _L, _L, _L, _P],
     "zk_embed_finish": [_P, _P, _P, _P, _L, _L, _L, _P],
     "zk_gather_rows": [_P, _P, _P, _P, _L, _L, _I, _P],
-    "zk_cross_entropy": [_P, _P, _P, _P, _L, _L, _L, _P],
-    "zk_sumsq": [_P, _P, _L, _F, _P],
+    "zk_cross_entropy": [_P, _P, _P, _P, _P, _L, _L, _L, _P],
+    "zk_sumsq": [_P, _P, _P, _L, _F, _P],
     "zk_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P, _F, _P],
     "zk_f32_to_bf16": [_P, _P, _L, _F, _I, _P],
-    "zk_f32_to_bf16_multi": [_P, _P, _P, _P, _I, _F, _P],
+    "zk_f32_to_bf16_multi": [_P, _P, _P, _P, _P, _P, _I, _F, _P],
     "zk_u8_resample_rows": [_P, _L, _L, _L, _L, _L, _L, c_uint32, _P, _P, _I, _L, _P, _P],
     "zk_u8_resample_cols": [_P, _L, _L, _P, _P, _I, _L, _P, _P],
     "zk_u8_patches_normalize": [_P, _L, _L, _L, _L, _L, c_uint32, _L, _L, _L, _P, _P, _I, _P],
@@ -62,7 +62,7 @@ for _name, _args in SIGNATURES.items():
     _fn.argtypes = _args
     _fn.restype = c_int
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 if lib.zk_abi_version() != ABI_VERSION:
     raise ImportError("libzero_hip.so ABI version mismatch; rebuild with `make -C zero_amd/csrc`")
 

@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* dy, const bf
 }
 
 // ---------------------------------------------------------------- column sum (bias grads)
-// block = 32 column-chunks (256 cols) x 8 row lanes; grid.y splits the rows.
+// block = 32 column-chunks (256 cols) x 8 row lanes; grid.y = nparts splits the rows.  Every block WRITES its
+// partial sums to out[part][col] (no atomics: the result does not depend on arrival order); the caller adds the
+// parts in index order (zk_f32_to_bf16_multi does, while converting).
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* dy, float* out, int rows, int N, int ld) {
   __shared__ float red[8][256 + 1];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* dy, float* ou
 #pragma unroll
   for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
   const int oc = blockIdx.x * 256 + threadIdx.x;
-  if (oc < N) atomicAdd(out + oc, t);
+  if (oc < N) out[(size_t)blockIdx.y * N + oc] = t;
 }
 
 // ---------------------------------------------------------------- patch embedding front end
@@ -230,7 +232,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* t0, cons
 // One 256-thread block per row.  Pass 1: online max / sum-exp (fp32).  Pass 2 (re-read, L2
 // resident: a 128256-wide bf16 row is 250 KiB): write softmax - onehot as bf16.
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const bf16_t* logits, const int32_t* targets,
-                                                            float* loss_sum, bf16_t* dlogits, int V, int ld) {
+                                                            float* loss_sum, float* row_loss, bf16_t* dlogits, int V,
+                                                            int ld) {
   __shared__ float red[8];
   const int row = blockIdx.x;
   const int tgt = targets[row];
@@ -238,6 +241,7 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const bf16_t* logits
   bf16_t* dx = dlogits ? dlogits + (size_t)row * ld : nullptr;
   const int nv = V >> 3;
   if (tgt == -100) {
+    if (row_loss && threadIdx.x == 0) row_loss[row] = -1.0f;       // marks "ignored" for the ordered sum
     if (dx) for (int i = threadIdx.x; i < nv; i += 256) *reinterpret_cast<u32x4*>(dx + (size_t)i * 8) = u32x4{0u, 0u, 0u, 0u};
     return;
   }
@@ -262,8 +266,9 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const bf16_t* logits
   s = (m == -INFINITY) ? 0.f : s * __expf(m - gm);
   const float gs = block_sum(s, red);
   if (threadIdx.x == 0) {
-    atomicAdd(loss_sum, logf(gs) + gm - xt);
-    atomicAdd(loss_sum + 1, 1.0f);
+    const float l = logf(gs) + gm - xt;      // >= 0 up to rounding; clamped so that -1 can mark ignored rows
+    if (row_loss) row_loss[row] = fmaxf(l, 0.f);
+    else { atomicAdd(loss_sum, l); atomicAdd(loss_sum + 1, 1.0f); }
   }
   if (dx) {
     const float inv = 1.0f / gs;
@@ -280,8 +285,25 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const bf16_t* logits
   }
 }
 
+// Ordered sum of the per-row losses: one block, thread t adds rows t, t + 256, ... in order, then a fixed tree.
+__global__ __launch_bounds__(256) void ce_finish_kernel(const float* row_loss, float* loss_sum, int rows) {
+  __shared__ float sl[256], sc[256];
+  float l = 0.f, c = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const float v = row_loss[r];
+    if (v >= 0.f) { l += v; c += 1.0f; }
+  }
+  sl[threadIdx.x] = l; sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { loss_sum[0] += sl[0]; loss_sum[1] += sc[0]; }
+}
+
 // ---------------------------------------------------------------- grad norm + AdamW
-__global__ __launch_bounds__(256) void sumsq_kernel(const bf16_t* g, float* out, int64_t n, float scale) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const bf16_t* g, float* out, float* parts, int64_t n, float scale) {
   __shared__ float red[8];
   float acc = 0.f;
   const int64_t nv = n >> 3;
@@ -294,7 +316,22 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const bf16_t* g, float* out,
   if (blockIdx.x == 0)
     for (int64_t i = nv * 8 + threadIdx.x; i < n; i += 256) { float t = bf2f(g[i]) * scale; acc += t * t; }
   float t = block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(out, t);
+  if (threadIdx.x == 0) {
+    if (parts) parts[blockIdx.x] = t;        // ordered finish below: the clip coefficient is reproducible
+    else atomicAdd(out, t);
+  }
+}
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* parts, float* out, int n) {
+  __shared__ float sl[256];
+  float l = 0.f;
+  for (int r = threadIdx.x; r < n; r += 256) l += parts[r];
+  sl[threadIdx.x] = l;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sl[threadIdx.x] += sl[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] += sl[0];
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(bf16_t* p, const bf16_t* g, float* m, float* v, int64_t n, float lr,
@@ -335,14 +372,18 @@ struct CvtSegs {
   bf16_t* dst[16];
   int n[16];
   int accumulate[16];
+  int nparts[16];       // src holds nparts rows of n values, `stride` elements apart: added in index order
+  long long stride[16];
 };
 __global__ __launch_bounds__(256) void f32_to_bf16_multi_kernel(CvtSegs t, float scale) {
   const int s = blockIdx.y;
   const float* src = t.src[s];
   bf16_t* dst = t.dst[s];
-  const int n = t.n[s], acc = t.accumulate[s];
+  const int n = t.n[s], acc = t.accumulate[s], np = t.nparts[s];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    float v = src[i] * scale;
+    float v = src[i];
+    for (int p = 1; p < np; ++p) v += src[(size_t)p * t.stride[s] + i];
+    v *= scale;
     if (acc) v += bf2f(dst[i]);
     dst[i] = f2bf(v);
   }
@@ -395,11 +436,10 @@ extern "C" int zk_act_bwd(const void* dy, const void* pre, void* dx, int64_t n, 
   return ZK_OK;
 }
 
-extern "C" int zk_colsum(const void* dy, float* out, int64_t rows, int64_t N, int64_t ld, hipStream_t stream) {
-  if (!dy || !out || rows <= 0 || N <= 0 || (N & 7) || (ld & 7)) return ZK_EINVAL;
-  int64_t gy = (rows + 63) / 64;
-  if (gy > 128) gy = 128;
-  dim3 grid((unsigned)((N + 255) / 256), (unsigned)gy);
+extern "C" int zk_colsum(const void* dy, float* out, int64_t rows, int64_t N, int64_t ld, int64_t nparts,
+                         hipStream_t stream) {
+  if (!dy || !out || rows <= 0 || N <= 0 || (N & 7) || (ld & 7) || nparts <= 0 || nparts > 65535) return ZK_EINVAL;
+  dim3 grid((unsigned)((N + 255) / 256), (unsigned)nparts);
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, (const bf16_t*)dy, out, (int)rows, (int)N, (int)ld);
   ZK_CHECK_LAUNCH();
   return ZK_OK;
@@ -434,19 +474,21 @@ extern "C" int zk_gather_rows(const void* table0, const void* table1, const int3
   return ZK_OK;
 }
 
-extern "C" int zk_cross_entropy(const void* logits, const int32_t* targets, float* loss_sum, void* dlogits, int64_t rows,
-                                int64_t V, int64_t ld, hipStream_t stream) {
-  if (!logits || !targets || !loss_sum || rows <= 0 || V <= 0 || (V & 7) || (ld & 7)) return ZK_EINVAL;
+extern "C" int zk_cross_entropy(const void* logits, const int32_t* targets, float* loss_sum, float* row_loss,
+                                void* dlogits, int64_t rows, int64_t V, int64_t ld, hipStream_t stream) {
+  if (!logits || !targets || !loss_sum || rows <= 0 || rows > 0x7FFFFFFF || V <= 0 || (V & 7) || (ld & 7)) return ZK_EINVAL;
   hipLaunchKernelGGL(cross_entropy_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const bf16_t*)logits, targets,
-                     loss_sum, (bf16_t*)dlogits, (int)V, (int)ld);
+                     loss_sum, row_loss, (bf16_t*)dlogits, (int)V, (int)ld);
+  if (row_loss) hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)row_loss, loss_sum, (int)rows);
   ZK_CHECK_LAUNCH();
   return ZK_OK;
 }
 
-extern "C" int zk_sumsq(const void* g, float* out, int64_t n, float scale, hipStream_t stream) {
+extern "C" int zk_sumsq(const void* g, float* out, float* parts, int64_t n, float scale, hipStream_t stream) {
   if (!g || !out || n <= 0) return ZK_EINVAL;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 8 + 1, 1024)), dim3(256), 0, stream, (const bf16_t*)g, out, n,
-                     scale);
+  const unsigned nb = grid_for(n / 8 + 1, ZK_SUMSQ_PARTS);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, stream, (const bf16_t*)g, out, parts, n, scale);
+  if (parts) hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)parts, out, (int)nb);
   ZK_CHECK_LAUNCH();
   return ZK_OK;
 }
@@ -472,7 +514,8 @@ extern "C" int zk_f32_to_bf16(const float* src, void* dst, int64_t n, float scal
 }
 
 extern "C" int zk_f32_to_bf16_multi(const float* const* src, void* const* dst, const int64_t* n, const int* accumulate,
-                                    int count, float scale, hipStream_t stream) {
+                                    const int* nparts, const int64_t* part_stride, int count, float scale,
+                                    hipStream_t stream) {
   if (!src || !dst || !n || !accumulate || count <= 0 || count > 16) return ZK_EINVAL;
   CvtSegs t;
   int64_t longest = 0;
@@ -480,6 +523,9 @@ extern "C" int zk_f32_to_bf16_multi(const float* const* src, void* const* dst, c
     const int j = i < count ? i : 0;
     if (!src[j] || !dst[j] || n[j] <= 0 || n[j] > 0x7FFFFFFF) return ZK_EINVAL;
     t.src[i] = src[j]; t.dst[i] = (bf16_t*)dst[j]; t.n[i] = (int)n[j]; t.accumulate[i] = accumulate[j];
+    t.nparts[i] = nparts ? nparts[j] : 1;
+    t.stride[i] = part_stride ? part_stride[j] : n[j];
+    if (t.nparts[i] < 1 || t.stride[i] < n[j]) return ZK_EINVAL;
     if (n[j] > longest) longest = n[j];
   }
   hipLaunchKernelGGL(f32_to_bf16_multi_kernel, dim3(grid_for(longest, 64), (unsigned)count), dim3(256), 0, stream, t, scale);

@@ -66,15 +66,19 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* x, con
 }
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
-// dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy   (fp32 atomics, one add per wave per column)
-template <int MAXV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
-                                                            const float* mean_i, const float* rstd_i,
-                                                            const bf16_t* dres, bf16_t* dx, float* dgamma,
-                                                            float* dbeta, int rows, int D) {
-  const int lane = threadIdx.x & 63;
-  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int nwaves = gridDim.x * 4;
+// dgamma_parts[block] = sum over this block's rows of dy * xhat ; dbeta_parts[block] = sum dy.
+// One workgroup of NW waves per part; a wave owns rows part*NW + wave (+ nparts*NW ...) and, when PF, requests
+// the NEXT row's x / dy / dres before it reduces the current one (a wave walks only a few rows: without the
+// prefetch every row pays a full dependent HBM round trip, 0.21 of peak in round 1).  The per-block sums are
+// combined through LDS in wave order and STORED (no atomics): the caller adds the parts in index order, so the
+// affine gradients are bit-reproducible.
+template <int MAXV, int NW, bool PF>
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
+                                                                const float* mean_i, const float* rstd_i,
+                                                                const bf16_t* dres, bf16_t* dx, float* dgamma,
+                                                                float* dbeta, int rows, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int stride = gridDim.x * NW;
   const int nv = D >> 3;
   float ag[MAXV][8], ab[MAXV][8];
 #pragma unroll
@@ -90,11 +94,25 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* dy, co
 #pragma unroll
       for (int j = 0; j < 8; ++j) gm[i][j] = 0.f;
   }
-  for (int row = wave_g; row < rows; row += nwaves) {
-    u32x4 vx[MAXV], vd[MAXV];
+  int row = blockIdx.x * NW + wave;
+  u32x4 vx[MAXV], vd[MAXV], vr[MAXV];
+  float mean = 0.f, rstd = 0.f;
+  if (row < rows) {
     load_row<MAXV>(vx, x + (size_t)row * D, nv, lane);
     load_row<MAXV>(vd, dy + (size_t)row * D, nv, lane);
-    const float mean = mean_i[row], rstd = rstd_i[row];
+    if (dres && dx) load_row<MAXV>(vr, dres + (size_t)row * D, nv, lane);
+    mean = mean_i[row]; rstd = rstd_i[row];
+  }
+  for (; row < rows; row += stride) {
+    u32x4 nx[MAXV], nd[MAXV], nr[MAXV];
+    float nmean = 0.f, nrstd = 0.f;
+    const int nrow = row + stride;
+    if (PF && nrow < rows) {
+      load_row<MAXV>(nx, x + (size_t)nrow * D, nv, lane);
+      load_row<MAXV>(nd, dy + (size_t)nrow * D, nv, lane);
+      if (dres && dx) load_row<MAXV>(nr, dres + (size_t)nrow * D, nv, lane);
+      nmean = mean_i[nrow]; nrstd = rstd_i[nrow];
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -119,7 +137,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* dy, co
         if (idx < nv) {
           float fx[8], fd[8], o[8], r[8];
           unpack8(vx[i], fx); unpack8(vd[i], fd);
-          if (dres) unpack8(*reinterpret_cast<const u32x4*>(dres + (size_t)row * D + (size_t)idx * 8), r);
+          if (dres) unpack8(vr[i], r);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             float xh = (fx[j] - mean) * rstd;
@@ -129,14 +147,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* dy, co
         }
       }
     }
+    if (PF) {
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) { vx[i] = nx[i]; vd[i] = nd[i]; vr[i] = nr[i]; }
+      mean = nmean; rstd = nrstd;
+    } else if (nrow < rows) {
+      load_row<MAXV>(vx, x + (size_t)nrow * D, nv, lane);
+      load_row<MAXV>(vd, dy + (size_t)nrow * D, nv, lane);
+      if (dres && dx) load_row<MAXV>(vr, dres + (size_t)nrow * D, nv, lane);
+      mean = mean_i[nrow]; rstd = rstd_i[nrow];
+    }
   }
   if (dgamma) {
-    // block-level reduction through LDS (the 4 waves take turns), then ONE atomic per column per
-    // block: with every wave adding into the same [D] words the kernel ran at the contended
-    // atomic rate (0.69 ms per call at 4616 x 1024; profiles/r01_bench_c3_kernel_stats_v1.csv).
     __shared__ float red[2][MAXV * 512];
-    const int wave = threadIdx.x >> 6;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
       if (wave == w) {
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
@@ -152,13 +176,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* dy, co
       }
       __syncthreads();
     }
-    // blocks start at staggered columns so concurrent blocks add into different words
-    const int rot = (blockIdx.x * 64) % D;
-    for (int c0 = threadIdx.x; c0 < D; c0 += 256) {
-      int c = c0 + rot;
-      if (c >= D) c -= D;
-      atomicAdd(dgamma + c, red[0][c]);
-      atomicAdd(dbeta + c, red[1][c]);
+    for (int c = threadIdx.x; c < D; c += 64 * NW) {
+      dgamma[(size_t)blockIdx.x * D + c] = red[0][c];
+      dbeta[(size_t)blockIdx.x * D + c] = red[1][c];
     }
   }
 }
@@ -246,8 +266,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXV <= 6 ?
 // dw[c] += sum_rows dy[r][c] * bf16(x[r][c] * rstd[r])   (the weight multiplies the bf16-rounded
 // normalised value, tf:llama:67).  Only trainable decoder layers need it (stage "pretrain": the
 // translator layer), so it is its own small kernel rather than a branch of rmsnorm_bwd: one block per
-// CU loops over rows with per-lane column sums in registers, block reduction through LDS, then one
-// atomic per column per block at staggered columns (as layernorm_bwd does for dgamma / dbeta).
+// CU loops over rows with per-lane column sums in registers, block reduction through LDS, then the block's
+// sums are STORED as part blockIdx.x of dw[nparts][D] (as layernorm_bwd does; the caller adds the parts in order).
 template <int MAXV>
 __global__ __launch_bounds__(256) void rmsnorm_dweight_kernel(const bf16_t* dy, const bf16_t* x, const float* rstd_i,
                                                               float* dw, int rows, int D) {
@@ -290,12 +310,7 @@ __global__ __launch_bounds__(256) void rmsnorm_dweight_kernel(const bf16_t* dy, 
     }
     __syncthreads();
   }
-  const int rot = (blockIdx.x * 64) % D;
-  for (int c0 = threadIdx.x; c0 < D; c0 += 256) {
-    int c = c0 + rot;
-    if (c >= D) c -= D;
-    atomicAdd(dw + c, red[c]);
-  }
+  for (int c = threadIdx.x; c < D; c += 256) dw[(size_t)blockIdx.x * D + c] = red[c];     // this block's part
 }
 
 // A handful of rows (single-token decoding steps): one 256-thread block per row, same arithmetic.
@@ -350,16 +365,19 @@ extern "C" int zk_layernorm_fwd(const void* x, const void* gamma, const void* be
 }
 
 extern "C" int zk_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
-                                const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D,
-                                hipStream_t stream) {
+                                const void* dres, void* dx, float* dgamma, float* dbeta, int64_t nparts, int64_t rows,
+                                int64_t D, hipStream_t stream) {
   if (!dy || !x || !gamma || !mean || !rstd || bad_dim(rows, D) || D > 4096) return ZK_EINVAL;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return ZK_EINVAL;
-  int64_t nb = (rows + 3) / 4;
-  if (nb > 256) nb = 256;   // one block per CU; every block ends with D atomics per affine vector
-  dim3 grid((unsigned)nb), block(256);
-#define CALL(V) hipLaunchKernelGGL((layernorm_bwd_kernel<V>), grid, block, 0, stream, (const bf16_t*)dy, \
+  if (dgamma ? (nparts < 1 || nparts > ZK_NORM_MAX_PARTS) : false) return ZK_EINVAL;
+  if (!dgamma) {                     // no affine gradients wanted: any grid will do
+    nparts = (rows + 7) / 8;
+    if (nparts > 512) nparts = 512;
+  }
+  dim3 grid((unsigned)nparts);
+#define CALL(V, NW, PF) hipLaunchKernelGGL((layernorm_bwd_kernel<V, NW, PF>), grid, dim3(64 * NW), 0, stream, (const bf16_t*)dy, \
     (const bf16_t*)x, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, (int)rows, (int)D)
-  if (D <= 1024) { CALL(2); } else { CALL(8); }
+  if (D <= 1024) { CALL(2, 8, true); } else { CALL(8, 4, false); }
 #undef CALL
   ZK_CHECK_LAUNCH();
   return ZK_OK;
@@ -395,12 +413,10 @@ extern "C" int zk_rmsnorm_bwd(const void* dy, const void* x, const void* w, cons
   return ZK_OK;
 }
 
-extern "C" int zk_rmsnorm_dweight(const void* dy, const void* x, const float* rstd, float* dweight, int64_t rows,
-                                  int64_t D, hipStream_t stream) {
-  if (!dy || !x || !rstd || !dweight || bad_dim(rows, D)) return ZK_EINVAL;
-  int64_t nb = (rows + 3) / 4;
-  if (nb > 256) nb = 256;
-  dim3 grid((unsigned)nb), block(256);
+extern "C" int zk_rmsnorm_dweight(const void* dy, const void* x, const float* rstd, float* dweight, int64_t nparts,
+                                  int64_t rows, int64_t D, hipStream_t stream) {
+  if (!dy || !x || !rstd || !dweight || bad_dim(rows, D) || nparts < 1 || nparts > ZK_NORM_MAX_PARTS) return ZK_EINVAL;
+  dim3 grid((unsigned)nparts), block(256);
 #define CALL(V) hipLaunchKernelGGL((rmsnorm_dweight_kernel<V>), grid, block, 0, stream, (const bf16_t*)dy, \
     (const bf16_t*)x, rstd, dweight, (int)rows, (int)D)
   DISPATCH_MAXV(D, CALL)

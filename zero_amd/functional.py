@@ -24,16 +24,15 @@ BF16 = torch.bfloat16
 # gradient sinks
 # ------------------------------------------------------------------------------------------
 class ZeroArena:
-    """fp32 scratch for the per-backward vector-gradient accumulators (bias / norm-affine sums): one
-    buffer, zeroed by ONE fill per backward, handed out in 64-element-aligned slices — instead of a
-    torch.zeros launch per accumulator (8 per encoder layer)."""
+    """fp32 scratch for the partial sums of the vector gradients (bias / norm-affine): one buffer handed out in
+    64-element-aligned slices and recycled after every layer's conversion launch (GradSink.flush) — the kernels
+    OVERWRITE their partial-sum slabs, so nothing is ever zero-filled (the name is historical)."""
 
-    def __init__(self, device, numel: int = 1 << 20):
-        self.buf = torch.zeros(numel, dtype=torch.float32, device=device)
+    def __init__(self, device, numel: int = 8 << 20):
+        self.buf = torch.empty(numel, dtype=torch.float32, device=device)
         self.ptr = 0
 
     def reset(self):
-        self.buf.zero_()
         self.ptr = 0
 
     def take(self, n: int) -> Optional[torch.Tensor]:
@@ -67,24 +66,26 @@ class GradSink:
             fn(p)
 
     @staticmethod
-    def zeros(n: int, device) -> torch.Tensor:
+    def parts(nparts: int, n: int, device) -> torch.Tensor:
+        """Uninitialised fp32 [nparts, n] slab for one vector gradient's partial sums."""
         a = GradSink.arena
         if a is not None and a.buf.device == torch.device(device):
-            t = a.take(n)
+            t = a.take(nparts * n)
             if t is not None:
-                return t
-        return torch.zeros(n, dtype=torch.float32, device=device)
+                return t.view(nparts, n)
+        return torch.empty((nparts, n), dtype=torch.float32, device=device)
 
     @staticmethod
     def flush():
         """One conversion launch for every vector gradient queued since the last flush (called at the
         end of each layer node's backward), then the slot notifications."""
-        if not GradSink.pending:
-            return
-        batch, GradSink.pending = GradSink.pending, []
-        ops.f32_to_bf16_multi_([(a, s_, acc) for a, s_, acc, _ in batch])
-        for _, _, _, p in batch:
-            GradSink.done(p)
+        if GradSink.pending:
+            batch, GradSink.pending = GradSink.pending, []
+            ops.f32_to_bf16_multi_([(a, s_, acc) for a, s_, acc, _ in batch])
+            for _, _, _, p in batch:
+                GradSink.done(p)
+        if GradSink.arena is not None:
+            GradSink.arena.reset()       # stream-ordered: the next layer's kernels run after this conversion
 
 
 # ------------------------------------------------------------------------------------------
@@ -182,25 +183,28 @@ def _wgrad(dy2d, x2d, w: torch.Tensor, need: bool):
     return ops.gemm(dy2d, x2d, trans_a=True, trans_b=True)
 
 
-def _vec_grad(acc_f32: torch.Tensor, p: torch.Tensor, need: bool):
-    """fp32 accumulated vector gradient (bias / norm affine) -> bf16 slot or autograd."""
+def _vec_grad(parts_f32: torch.Tensor, p: torch.Tensor, need: bool):
+    """fp32 partial sums [nparts, n] of a vector gradient (bias / norm affine) -> bf16 slot or autograd."""
     if not need:
         return None
     slot = GradSink.slot(p)
     if slot is not None:
-        GradSink.pending.append((acc_f32, slot, GradSink.is_dirty(p), p))   # converted by GradSink.flush()
+        GradSink.pending.append((parts_f32, slot, GradSink.is_dirty(p), p))   # summed + converted by GradSink.flush()
         return None
     out = torch.empty(p.shape, dtype=BF16, device=p.device)
-    ops.f32_to_bf16_(acc_f32, out)
+    ops.f32_to_bf16_multi_([(parts_f32, out.view(-1), False)])
     return out
+
+
+def _colsum(dy2d) -> torch.Tensor:
+    parts = GradSink.parts(ops.colsum_parts(dy2d.shape[0]), dy2d.shape[1], dy2d.device)
+    return ops.colsum_(dy2d, parts)
 
 
 def _bias_grad(dy2d, b: torch.Tensor, need: bool):
     if not need:
         return None
-    acc = GradSink.zeros(b.numel(), dy2d.device)
-    ops.colsum_(dy2d, acc)
-    return _vec_grad(acc, b, True)
+    return _vec_grad(_colsum(dy2d), b, True)
 
 
 def adjacent(*ts: torch.Tensor) -> bool:
@@ -283,8 +287,9 @@ class LayerNormFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         D = x2.shape[1]
-        dg = GradSink.zeros(D, x2.device) if need_p else None
-        db = GradSink.zeros(D, x2.device) if need_p else None
+        npn = ops.norm_parts(x2.shape[0])
+        dg = GradSink.parts(npn, D, x2.device) if need_p else None
+        db = GradSink.parts(npn, D, x2.device) if need_p else None
         dx = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, dgamma=dg, dbeta=db, need_dx=ctx.needs_input_grad[0])
         out = (dx.view(dy.shape) if dx is not None else None, _vec_grad(dg, gamma, ctx.needs_input_grad[1]),
                _vec_grad(db, beta, ctx.needs_input_grad[2]), None)
@@ -363,7 +368,7 @@ class EncoderLayerFn(torch.autograd.Function):
         dy2 = dy.reshape(M, D)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        f32 = lambda n: GradSink.zeros(n, dev)
+        f32 = lambda n: GradSink.parts(ops.norm_parts(M), n, dev)      # LayerNorm affine partial sums
         # ---- MLP block:  y = xa + fc2(quick_gelu(fc1(LN2(xa))))
         d_pre = dgrad_trainable(dy2, f2w, epilogue=ops.EPI_MUL_DQUICK_GELU, aux_in=pre)
         g_f2w = _wgrad(dy2, act, f2w, nig[15])
@@ -398,11 +403,10 @@ class EncoderLayerFn(torch.autograd.Function):
             g_kw = _wgrad(d_qkv[:, D:2 * D], h1, kw, nig[5])
             g_vw = _wgrad(d_qkv[:, 2 * D:], h1, vw, nig[7])
         if nig[4] or nig[6] or nig[8]:
-            acc = f32(3 * D)
-            ops.colsum_(d_qkv, acc)
-            g_qb = _vec_grad(acc[:D], qb, nig[4])
-            g_kb = _vec_grad(acc[D:2 * D], kb, nig[6])
-            g_vb = _vec_grad(acc[2 * D:], vb, nig[8])
+            acc = _colsum(d_qkv)                       # [nparts, 3D]: column slices keep the part stride
+            g_qb = _vec_grad(acc[:, :D], qb, nig[4])
+            g_kb = _vec_grad(acc[:, D:2 * D], kb, nig[6])
+            g_vb = _vec_grad(acc[:, 2 * D:], vb, nig[8])
         need_dx = nig[0]
         dx = None
         g_l1w = g_l1b = None
@@ -493,7 +497,7 @@ class DecoderLayerFn(torch.autograd.Function):
         dy2 = dy.reshape(M, d)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        f32 = lambda n: GradSink.zeros(n, dy.device)
+        f32 = lambda n: GradSink.parts(ops.norm_parts(M), n, dy.device)      # RMSNorm weight partial sums
         wgu = packed_rows(gw, uw)
         g_dw = _wgrad(dy2, hm, dw, nig[9])
         if ctx.fused_swiglu:
@@ -614,9 +618,7 @@ class SpliceFn(torch.autograd.Function):
                 outs.append(None)
                 continue
             rows = ops.gather_rows(dy2, None, pos, d)
-            acc = GradSink.zeros(d, dy.device)
-            ops.colsum_(rows, acc)
-            outs.append(_vec_grad(acc, p, True))
+            outs.append(_vec_grad(_colsum(rows), p, True))
         GradSink.flush()
         return (d_img, outs[0], outs[1]) + (None,) * 7
 

@@ -277,8 +277,17 @@ def layernorm_fwd(x, gamma, beta, eps: float, save_stats: bool = True):
     return y, mean, rstd
 
 
+NORM_MAX_PARTS = 512
+
+
+def norm_parts(rows: int) -> int:
+    """Partial-sum count for the norm weight gradients: about 16 rows per workgroup."""
+    return max(1, min(NORM_MAX_PARTS, (rows + 15) // 16))
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, need_dx: bool = True):
-    """dx = dres + LN'(dy); dgamma/dbeta (fp32 [D]) are accumulated into when given."""
+    """dx = dres + LN'(dy).  dgamma / dbeta: fp32 [nparts, D] buffers that are OVERWRITTEN with partial sums
+    (deterministic; add the parts in order — f32_to_bf16_multi_ does)."""
     _chk2d(dy, "dy"); _chk2d(x, "x")
     if not (dy.is_contiguous() and x.is_contiguous()):
         raise ValueError("layernorm_bwd: contiguous inputs required")
@@ -286,8 +295,14 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, 
     dx = torch.empty_like(x) if need_dx else None
     if dres is not None and not dres.is_contiguous():
         raise ValueError("layernorm_bwd: dres must be contiguous")
+    nparts = 0
+    if dgamma is not None:
+        if (dbeta is None or dgamma.shape != dbeta.shape or dgamma.dim() != 2 or dgamma.shape[1] != D
+                or dgamma.dtype != torch.float32 or not (dgamma.is_contiguous() and dbeta.is_contiguous())):
+            raise ValueError("layernorm_bwd: dgamma / dbeta must be contiguous fp32 [nparts, D]")
+        nparts = dgamma.shape[0]
     check(lib.zk_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dgamma), _p(dbeta),
-                               rows, D, _stream()), "zk_layernorm_bwd")
+                               nparts, rows, D, _stream()), "zk_layernorm_bwd")
     return dx
 
 
@@ -312,14 +327,15 @@ def rmsnorm_bwd(dy, x, w, rstd, dres=None):
     return dx
 
 
-def rmsnorm_dweight_(dy, x, rstd, dw_f32):
-    """dw_f32 (fp32 [D]) += sum_rows dy * bf16(x * rstd)."""
-    _chk2d(dy, "dy"); _chk2d(x, "x"); _chk_flat(dw_f32, "dw", torch.float32); _chk_flat(rstd, "rstd", torch.float32)
-    if not (dy.is_contiguous() and x.is_contiguous()) or dy.shape != x.shape or dw_f32.numel() != x.shape[1]:
-        raise ValueError("rmsnorm_dweight: contiguous [rows, D] inputs and an fp32 [D] accumulator required")
-    check(lib.zk_rmsnorm_dweight(_p(dy), _p(x), _p(rstd), _p(dw_f32), x.shape[0], x.shape[1], _stream()),
-          "zk_rmsnorm_dweight")
-    return dw_f32
+def rmsnorm_dweight_(dy, x, rstd, dw_parts):
+    """dw_parts (fp32 [nparts, D], overwritten) = partial sums over rows of dy * bf16(x * rstd)."""
+    _chk2d(dy, "dy"); _chk2d(x, "x"); _chk_flat(rstd, "rstd", torch.float32)
+    if (not (dy.is_contiguous() and x.is_contiguous()) or dy.shape != x.shape or dw_parts.dim() != 2
+            or dw_parts.shape[1] != x.shape[1] or dw_parts.dtype != torch.float32 or not dw_parts.is_contiguous()):
+        raise ValueError("rmsnorm_dweight: contiguous [rows, D] inputs and an fp32 [nparts, D] buffer required")
+    check(lib.zk_rmsnorm_dweight(_p(dy), _p(x), _p(rstd), _p(dw_parts), dw_parts.shape[0], x.shape[0], x.shape[1],
+                                 _stream()), "zk_rmsnorm_dweight")
+    return dw_parts
 
 
 def rope_(x2d, cos_t, sin_t, S: int, heads: int, hd: int, inverse: bool = False):
@@ -351,10 +367,19 @@ def swiglu_bwd(dh, gu, F: int):
     return dgu
 
 
-def colsum_(dy, out_f32):
-    _chk2d(dy, "dy"); _chk_flat(out_f32, "out", torch.float32)
-    check(lib.zk_colsum(_p(dy), _p(out_f32), dy.shape[0], dy.shape[1], dy.stride(0), _stream()), "zk_colsum")
-    return out_f32
+def colsum_parts(rows: int) -> int:
+    return max(1, min(128, rows // 64))
+
+
+def colsum_(dy, out_parts):
+    """out_parts (fp32 [nparts, N], overwritten) = partial column sums of dy (deterministic; add the parts in order)."""
+    _chk2d(dy, "dy")
+    if (out_parts.dim() != 2 or out_parts.shape[1] != dy.shape[1] or out_parts.dtype != torch.float32
+            or not out_parts.is_contiguous()):
+        raise ValueError("colsum: out must be a contiguous fp32 [nparts, N] buffer")
+    check(lib.zk_colsum(_p(dy), _p(out_parts), dy.shape[0], dy.shape[1], dy.stride(0), out_parts.shape[0], _stream()),
+          "zk_colsum")
+    return out_parts
 
 
 def act_bwd(dy, pre, kind: int, out=None):
@@ -397,13 +422,15 @@ def cross_entropy(logits, targets_i32, loss_acc, dlogits=None):
     """loss_acc (fp32[2]) += [sum of row losses, number of non-ignored rows]."""
     _chk2d(logits, "logits")
     rows, V = logits.shape
-    check(lib.zk_cross_entropy(_p(logits), _p(targets_i32), _p(loss_acc), _p(dlogits), rows, V, logits.stride(0),
-                               _stream()), "zk_cross_entropy")
+    row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)      # ordered (reproducible) loss sum
+    check(lib.zk_cross_entropy(_p(logits), _p(targets_i32), _p(loss_acc), _p(row_loss), _p(dlogits), rows, V,
+                               logits.stride(0), _stream()), "zk_cross_entropy")
     return loss_acc
 
 
 def sumsq_(g_flat, out_f32, scale: float = 1.0):
-    check(lib.zk_sumsq(_p(g_flat), _p(out_f32), g_flat.numel(), float(scale), _stream()), "zk_sumsq")
+    parts = torch.empty(1024, dtype=torch.float32, device=g_flat.device)          # ZK_SUMSQ_PARTS: ordered block sums
+    check(lib.zk_sumsq(_p(g_flat), _p(out_f32), _p(parts), g_flat.numel(), float(scale), _stream()), "zk_sumsq")
     return out_f32
 
 
@@ -420,21 +447,32 @@ def f32_to_bf16_(src, dst, scale: float = 1.0, accumulate: bool = False):
 
 
 def f32_to_bf16_multi_(pairs, scale: float = 1.0):
-    """pairs: list of (src fp32 flat, dst bf16 flat, accumulate) — ONE launch per 16 segments."""
-    import ctypes
+    """pairs: list of (src fp32 [nparts, n] partial sums (or flat [n]), dst bf16 flat [n], accumulate) — the parts
+    are added in index order; ONE launch per 16 segments.  src rows may be strided column slices."""
     for i in range(0, len(pairs), 16):
         chunk = pairs[i:i + 16]
         k = len(chunk)
+        np_, st_ = [], []
+        for s_, d_, _ in chunk:
+            if s_.dim() == 1:
+                s_parts, s_n, s_stride = 1, s_.numel(), s_.numel()
+                ok = s_.is_contiguous()
+            else:
+                s_parts, s_n = s_.shape
+                s_stride = s_.stride(0) if s_parts > 1 else s_n
+                ok = s_.dim() == 2 and s_.stride(1) == 1
+            if s_.dtype != torch.float32 or d_.dtype != BF16 or s_n != d_.numel() or not ok or not d_.is_contiguous():
+                raise ValueError("f32_to_bf16_multi: (fp32 [nparts, n], bf16 [n]) pairs required")
+            np_.append(s_parts); st_.append(s_stride)
         srcs = (ctypes.c_void_p * k)(*[s_.data_ptr() for s_, _, _ in chunk])
         dsts = (ctypes.c_void_p * k)(*[d_.data_ptr() for _, d_, _ in chunk])
-        ns = (ctypes.c_int64 * k)(*[s_.numel() for s_, _, _ in chunk])
+        ns = (ctypes.c_int64 * k)(*[d_.numel() for _, d_, _ in chunk])
         accs = (ctypes.c_int * k)(*[int(a_) for _, _, a_ in chunk])
-        for s_, d_, _ in chunk:
-            if s_.dtype != torch.float32 or d_.dtype != BF16 or s_.numel() != d_.numel() or not (
-                    s_.is_contiguous() and d_.is_contiguous()):
-                raise ValueError("f32_to_bf16_multi: (fp32, bf16) contiguous pairs of equal length required")
+        nps = (ctypes.c_int * k)(*np_)
+        sts = (ctypes.c_int64 * k)(*st_)
         check(lib.zk_f32_to_bf16_multi(ctypes.cast(srcs, ctypes.c_void_p), ctypes.cast(dsts, ctypes.c_void_p),
-                                       ctypes.cast(ns, ctypes.c_void_p), ctypes.cast(accs, ctypes.c_void_p), k,
+                                       ctypes.cast(ns, ctypes.c_void_p), ctypes.cast(accs, ctypes.c_void_p),
+                                       ctypes.cast(nps, ctypes.c_void_p), ctypes.cast(sts, ctypes.c_void_p), k,
                                        float(scale), _stream()), "zk_f32_to_bf16_multi")
 
 

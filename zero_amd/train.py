@@ -83,6 +83,12 @@ class Trainer:
 
     def optimizer_step(self):
         r, cfg = self.reducer, self.cfg
+        for p in r.params:
+            # every trainable gradient must have gone through the flat slots (the ZF layer nodes); a parameter that
+            # was used through plain autograd (e.g. Zero._forward's torch.cat on embd_soi) would be silently ignored
+            if p.grad is not None:
+                raise RuntimeError(f"{r.names[id(p)]} received an autograd .grad outside the flat gradient buffer: "
+                                   "drive the Trainer through forward_hf / forward_from_ids, not Zero._forward")
         self.global_step += 1
         bump_weights_epoch()           # the fused AdamW below writes the parameters through raw pointers
         self.sumsq.zero_()
