@@ -149,3 +149,41 @@ def test_two_rank_gloo():
         p.join(timeout=30)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_thread_comm_rendezvous_cpu():
+    """The rank-thread communicator the one-GPU DDP test runs on: async all-reduce never blocks the caller, sums in
+    rank order, broadcast copies rank 0; mismatched sizes (collectives issued in different orders) raise."""
+    import threading
+    from zero_amd.distributed.comm import ThreadGroup, use_comm
+    from zero_amd.distributed.torchshard import reduce_sum_pair
+    W = 3
+    group = ThreadGroup(W)
+    out, errs = {}, []
+
+    def main(r):
+        try:
+            c = group.comm(r)
+            b = torch.full((4,), float(r + 1))
+            c.broadcast(b, src=0)
+            t1, t2 = torch.full((5,), float(r + 1)), torch.full((2,), 10.0 * (r + 1))
+            h1 = c.all_reduce_async(t1)          # returns at once even though the other ranks are not there yet
+            h2 = c.all_reduce_async(t2)
+            h1.wait(); h2.wait()
+            with use_comm(c):
+                l, n = reduce_sum_pair(torch.tensor(float(r + 1), requires_grad=True) * 2.0, torch.tensor(r + 1))
+            out[r] = (b, t1, t2, l.item(), n.item())
+        except BaseException as e:  # noqa: BLE001
+            errs.append(repr(e))
+    ths = [threading.Thread(target=main, args=(r,)) for r in range(W)]
+    [t.start() for t in ths]
+    [t.join(timeout=60) for t in ths]
+    assert not errs, errs
+    for r in range(W):
+        b, t1, t2, l, n = out[r]
+        assert torch.all(b == 1.0) and torch.all(t1 == 6.0) and torch.all(t2 == 60.0) and l == 12.0 and n == 6
+    g2 = ThreadGroup(2)
+    c0, c1 = g2.comm(0), g2.comm(1)
+    c0.all_reduce_async(torch.zeros(3))
+    with pytest.raises(RuntimeError):
+        c1.all_reduce_async(torch.zeros(4))

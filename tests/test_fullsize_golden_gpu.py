@@ -155,6 +155,11 @@ def _golden_parity(fx, gold):
         fl_m = ((tfb - ref).abs().max() / amax).item()
         nrm = abs(g.float().norm().item() - gold["fp32.gradnorm." + n].item()) / max(gold["fp32.gradnorm." + n].item(),
                                                                                     1e-3 * scale * g.numel() ** 0.5)
+        if ref.norm().item() < zero_floor:
+            # analytically zero (k_proj.bias): rounding noise on both sides, judged against the size of the real
+            # gradients only (a noise-vs-noise "closer than transformers" comparison says nothing)
+            assert e_f <= 5e-2 and nrm <= 5e-2, (n, e_f, nrm)
+            continue
         rows.append((e_f, fl_f, e_m, fl_m, nrm, n))
     rows.sort(reverse=True)
     rep["worst gradients (frob hip, frob floor, maxrel hip, maxrel floor, norm err, name)"] = rows[:5]

@@ -33,6 +33,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from ..functional import GradSink
+from .comm import TorchComm
 
 _DEBUG = os.environ.get("ZERO_AMD_DDP_DEBUG") == "1"
 # (gloo on DEVICE tensors is not a usable rehearsal of this path on a one-GPU box: several of its
@@ -75,9 +76,10 @@ def _pack_groups(params: List[nn.Parameter]) -> List[List[nn.Parameter]]:
 
 
 class FlatGradReducer:
-    def __init__(self, model: nn.Module, bucket_bytes: int = 25 * 1024 * 1024, process_group=None):
+    def __init__(self, model: nn.Module, bucket_bytes: int = 25 * 1024 * 1024, process_group=None, comm=None):
+        self.comm = comm if comm is not None else TorchComm(process_group)     # RCCL unless a test passes its own
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.world = self.comm.world
         # one-GPU rehearsal of the collective path (bench.py --force-dist): issue the all-reduces
         # of a 1-rank group instead of skipping them
         self._force = dist.is_initialized() and os.environ.get("ZERO_AMD_FORCE_ALLREDUCE") == "1"
@@ -107,8 +109,7 @@ class FlatGradReducer:
                 self.offset[id(p)] = o
         if self.world > 1:
             # DDP's _sync_module_states: every replica starts from rank 0's trainable parameters
-            src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
-            dist.broadcast(self.flat_param, src=src, group=process_group)
+            self.comm.broadcast(self.flat_param, src=0)
         # contiguous buckets
         self.buckets: List[dict] = []
         cur = dict(start=0, end=0, params=[])
@@ -175,8 +176,7 @@ class FlatGradReducer:
         b = self.buckets[i]
         if _DEBUG:
             _dbg(f"launch bucket {i} [{b['start']}:{b['end']}) of {len(self.buckets)}")
-        self._handles.append(dist.all_reduce(self.flat_grad[b["start"]:b["end"]], op=dist.ReduceOp.SUM,
-                                             group=self.pg, async_op=True))
+        self._handles.append(self.comm.all_reduce_async(self.flat_grad[b["start"]:b["end"]]))
         self._launched[i] = True
 
     def finish_backward(self):

@@ -3,18 +3,19 @@
 (RCCL on MI355X: the "nccl" backend of torch.distributed), backward = identity, so each rank
 back-propagates local_loss_sum / global_token_count."""
 import torch
-import torch.distributed as dist
+
+from .comm import current_comm
 
 
 def _world_size() -> int:
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    return current_comm().world
 
 
 def _reduce(tensor: torch.Tensor) -> torch.Tensor:
-    if _world_size() == 1:
+    comm = current_comm()          # torch.distributed (RCCL) unless the calling thread installed a test group
+    if comm.world == 1:
         return tensor
-    dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
-    return tensor
+    return comm.all_reduce(tensor)
 
 
 class Reduce(torch.autograd.Function):
@@ -41,7 +42,7 @@ def reduce_sum_pair(loss_sum: torch.Tensor, num_tokens: torch.Tensor):
     if _world_size() == 1:
         return loss_sum, num_tokens
     buf = torch.stack([loss_sum.detach().double(), num_tokens.double()])
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    current_comm().all_reduce(buf)
     total = buf[0].to(loss_sum.dtype)
     # value = global sum, gradient = identity w.r.t. the local sum
     loss_out = loss_sum + (total - loss_sum.detach())

@@ -16,16 +16,19 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .distributed.comm import use_comm
 from .distributed.ddp import FlatGradReducer
 from .functional import GradSink, ZeroArena, bump_weights_epoch
 
 
 class Trainer:
     def __init__(self, cfg, model: nn.Module, forward_fn: Callable, optim_groups: List[dict], *,
-                 total_steps: int = 1000, warmup_steps: int = 0, process_group=None, bucket_bytes=25 << 20):
+                 total_steps: int = 1000, warmup_steps: int = 0, process_group=None, bucket_bytes=25 << 20,
+                 comm=None):
         self.cfg, self.model = cfg, model
         self.forward = forward_fn.__get__(model, model.__class__)          # train.py:213-214
-        self.reducer = FlatGradReducer(model, bucket_bytes=bucket_bytes, process_group=process_group)
+        self.comm = comm             # None: torch.distributed (RCCL); tests pass a rank-thread communicator
+        self.reducer = FlatGradReducer(model, bucket_bytes=bucket_bytes, process_group=process_group, comm=comm)
         r = self.reducer
         dev = r.flat_param.device
         self.m = torch.zeros(r.numel, dtype=torch.float32, device=dev)
@@ -65,7 +68,11 @@ class Trainer:
         last = (self._micro + 1) % self.accum == 0
         if self._micro % self.accum == 0:
             r.begin_step()
-        loss = self.forward(self.cfg, *fwd_args, **fwd_kwargs)             # train.py:524
+        if self.comm is not None:
+            with use_comm(self.comm):                                       # the forward's scalar reductions
+                loss = self.forward(self.cfg, *fwd_args, **fwd_kwargs)
+        else:
+            loss = self.forward(self.cfg, *fwd_args, **fwd_kwargs)         # train.py:524
         scaled = loss / self.accum                                          # train.py:527
         GradSink.arena = self.arena
         self.arena.reset()
