@@ -253,6 +253,18 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     images_per_s = B * world * args.steps / dt
 
+    # ---- host cost of enqueuing one step, measured with an EMPTY device queue (the in-loop figure above also
+    # counts the time Python spends blocked on a full launch queue, i.e. it approaches the GPU time of a step
+    # whenever the GPU is the bottleneck).  Outside the timed region; every rank takes the same steps.
+    host_enq = []
+    for _ in range(3):
+        barrier()
+        h0 = time.perf_counter()
+        step()
+        host_enq.append((time.perf_counter() - h0) * 1e3)
+    barrier()
+    host_enqueue_ms = sorted(host_enq)[1]
+
     # ---- per-kernel timing of the GEMMs, live, with HIP events on the launch stream.  Every
     # zk_gemm_bf16 call (plain and fused) is bracketed by two events and attributed to the kernel
     # variant the library launched (zk_gemm_last_plan), so each group below is ONE kernel symbol of
@@ -406,6 +418,7 @@ def main():
             "tflop_per_image_algorithmic": round(fl_alg / 1e12, 3),
             "tflop_per_image_executed": round(fl_exec / 1e12, 3),
             "mfma_util_step": round(per_gpu * fl_exec / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "host_enqueue_ms_per_step": round(host_enqueue_ms, 2),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         _emit(out)

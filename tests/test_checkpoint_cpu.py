@@ -78,3 +78,62 @@ def test_load_reference_style_keys_and_guards(tmp_path):
     assert load_checkpoint("/nonexistent.pth", model, dry_load_mode=True) == (0, 0)
     with pytest.raises(AssertionError):
         load_checkpoint("/nonexistent.pth", model)
+
+
+def test_trainer_state_dict_is_torch_adamw_layout(tmp_path):
+    """The reference saves ``optimizer.state_dict()`` of torch.optim.AdamW and ``scheduler.state_dict()`` of
+    CosineAnnealingLR (ref:train.py:382-414, ref:utils.py:357-377).  The Trainer's state dicts must load into those
+    torch objects, and theirs into the Trainer, through a real checkpoint file (weights_only=True)."""
+    from zero_amd.train import Trainer
+    cfg, model, _ = _model()
+    groups = func_optim_filter(cfg, model)
+    tr = Trainer(cfg, model, lambda self, c: None, groups, total_steps=40)
+    try:
+        # the reference's side: torch AdamW over the same groups, two steps with synthetic gradients
+        ref_groups = func_optim_filter(cfg, model)       # same parameters, same order
+        opt = torch.optim.AdamW(ref_groups, betas=(cfg.adamw_beta1, cfg.adamw_beta2), eps=1e-8)
+        sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=40, eta_min=0.0)
+        g = torch.Generator().manual_seed(5)
+        for _ in range(2):
+            for grp in ref_groups:
+                for p in grp["params"]:
+                    p.grad = (0.01 * torch.randn(p.shape, generator=g)).to(p.dtype)
+            opt.step(); sch.step()
+        for grp in ref_groups:
+            for p in grp["params"]:
+                p.grad = None
+        args = types.SimpleNamespace(ckpt_dir=str(tmp_path), exp_code="interop")
+        path = save_checkpoint(args, model, opt, sch, epoch=0, global_step=2)        # a reference-style file
+        # ... loads into the Trainer
+        assert load_checkpoint(path, model, optimizer=tr, scheduler=tr.scheduler, strict=False) == (0, 2)
+        assert tr.global_step == 2
+        flat = [p for grp in ref_groups for p in grp["params"]]
+        for i, p in enumerate(flat):
+            o, n = tr.reducer.offset[id(p)], p.numel()
+            assert torch.equal(tr.m[o:o + n], opt.state[p]["exp_avg"].reshape(-1).float()), i
+            assert torch.equal(tr.v[o:o + n], opt.state[p]["exp_avg_sq"].reshape(-1).float()), i
+        # the Trainer's file loads into fresh torch objects
+        path2 = save_checkpoint(args, model, tr, tr.scheduler, epoch=0, global_step=tr.global_step + 1000)
+        opt2 = torch.optim.AdamW(func_optim_filter(cfg, model), betas=(cfg.adamw_beta1, cfg.adamw_beta2), eps=1e-8)
+        sch2 = torch.optim.lr_scheduler.CosineAnnealingLR(opt2, T_max=40, eta_min=0.0)
+        ck = torch.load(path2, map_location="cpu", weights_only=True)
+        assert set(ck["optimizer"]) == {"state", "param_groups"}
+        assert [g_["params"] for g_ in ck["optimizer"]["param_groups"]] == [g_["params"] for g_ in opt.state_dict()["param_groups"]]
+        opt2.load_state_dict(ck["optimizer"])
+        sch2.load_state_dict(ck["scheduler"])
+        assert sch2.last_epoch == 2
+        for p in flat:
+            assert torch.equal(opt2.state[p]["exp_avg"].float(), opt.state[p]["exp_avg"].float())
+            assert float(opt2.state[p]["step"]) == 2.0
+        # the cosine factor both sides apply at step 2 is the same
+        assert abs(sch.get_last_lr()[0] / sch.base_lrs[0] - tr.lr_factor(2)) < 1e-6
+        # a structurally different optimizer state is rejected loudly and the schedule still resumes at the file's step
+        bad = {"state": {}, "param_groups": [{"params": [0, 1]}]}
+        with pytest.raises(ValueError):
+            tr.load_state_dict(bad)
+        torch.save({"epoch": 3, "global_step": 77, "model": {}, "optimizer": bad, "scheduler": None},
+                   os.path.join(str(tmp_path), "bad.pth"))
+        assert load_checkpoint(os.path.join(str(tmp_path), "bad.pth"), model, optimizer=tr, strict=False) == (3, 77)
+        assert tr.global_step == 77
+    finally:
+        tr.reducer.close()

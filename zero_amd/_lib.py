@@ -8,7 +8,9 @@ import os
 from ctypes import c_float, c_int, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzero_hip.so")
+# ZERO_AMD_LIB: an alternative build of the same ABI (A/B runs of two kernel versions on one device, -DZK_ABLATION
+# timing builds); never a fallback — the file must exist
+LIB_PATH = os.environ.get("ZERO_AMD_LIB") or os.path.join(_HERE, "libzero_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

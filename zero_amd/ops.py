@@ -20,7 +20,14 @@ EPI_SWIGLU, EPI_SWIGLU_BWD = 5, 6
 BF16 = torch.bfloat16
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """hipStream_t of torch's current stream on the current device (the raw getter is ~20x cheaper than building a
+    torch.cuda.Stream object per launch: 500 launches per step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -56,7 +63,7 @@ WORKSPACE_BYTES = 160 << 20
 def _workspace(device) -> torch.Tensor:
     """fp32 scratch for split-K GEMMs, one per (device, stream) — two streams that each run a split-K product
     must not share partial slabs — allocated on first use (the C ABI never allocates)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _stream())
     ws = _WORKSPACE.get(key)
     if ws is None:
         ws = _WORKSPACE[key] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)

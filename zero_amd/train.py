@@ -50,6 +50,10 @@ class Trainer:
             else:
                 segs.append([o, e, h])
         self.segments = segs
+        # torch.optim layout bookkeeping (state_dict / load_state_dict): parameter index = position in the
+        # concatenation of the reference-style groups, as torch.optim.Optimizer numbers them
+        self._groups = [dict(params=[p for p in g["params"] if id(p) in r.offset], lr=float(g["lr"]),
+                             weight_decay=float(g.get("weight_decay", 0.0))) for g in optim_groups]
         self.total_steps, self.warmup_steps = total_steps, warmup_steps
         self.global_step = 0
         self.accum = max(1, int(cfg.gradient_accumulation_steps))
@@ -113,24 +117,80 @@ class Trainer:
     def grad_norm(self) -> torch.Tensor:
         return self.sumsq.sqrt()
 
-    # ---- optimizer state for utils.save_checkpoint / load_checkpoint (ref:utils.py:357-360,504-508)
+    # ---- optimizer / scheduler state in torch's own layouts (ref:utils.py:357-377,504-514 save and load
+    # ``optimizer.state_dict()`` of torch.optim.AdamW and ``scheduler.state_dict()`` of CosineAnnealingLR)
     def state_dict(self) -> dict:
-        """Adam moments per parameter NAME (layout independent), fp32, plus the step counters."""
-        r = self.reducer
-        m, v = {}, {}
-        for p in r.params:
-            o, n = r.offset[id(p)], p.numel()
-            m[r.names[id(p)]] = self.m[o:o + n].detach().to("cpu", copy=True).view(p.shape)
-            v[r.names[id(p)]] = self.v[o:o + n].detach().to("cpu", copy=True).view(p.shape)
-        return {"exp_avg": m, "exp_avg_sq": v, "global_step": self.global_step, "micro": self._micro}
+        """torch.optim.AdamW layout: ``state[i] = {step, exp_avg, exp_avg_sq}`` with i numbering the parameters of
+        the reference-style groups in order, ``param_groups`` with the hyper-parameters and index lists.  The
+        moments are this Trainer's fp32 ones (torch casts them to the parameter dtype on load)."""
+        r, cfg = self.reducer, self.cfg
+        state, groups, i = {}, [], 0
+        f = self.lr_factor(self.global_step) if self.global_step > 0 else (0.0 if self.warmup_steps > 0 else 1.0)
+        for g in self._groups:
+            idx = []
+            for p in g["params"]:
+                if self.global_step > 0:
+                    o, n = r.offset[id(p)], p.numel()
+                    state[i] = {"step": torch.tensor(float(self.global_step)),
+                                "exp_avg": self.m[o:o + n].detach().to("cpu", copy=True).view(p.shape),
+                                "exp_avg_sq": self.v[o:o + n].detach().to("cpu", copy=True).view(p.shape)}
+                idx.append(i)
+                i += 1
+            groups.append({"lr": g["lr"] * f, "initial_lr": g["lr"], "betas": (float(cfg.adamw_beta1), float(cfg.adamw_beta2)),
+                           "eps": 1e-8, "weight_decay": g["weight_decay"], "amsgrad": False, "maximize": False,
+                           "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                           "decoupled_weight_decay": True, "params": idx})
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd: dict):
+        """Accepts torch.optim.AdamW's layout (a checkpoint written by the reference, moments in any float dtype)
+        and the name-keyed layout of round 1.  Raises on a structural mismatch (utils.load_checkpoint reports it
+        and falls back to the checkpoint's global_step, as the reference's try / except does)."""
         r = self.reducer
-        for p in r.params:
-            o, n, name = r.offset[id(p)], p.numel(), r.names[id(p)]
-            if name in sd["exp_avg"]:
-                self.m[o:o + n].copy_(sd["exp_avg"][name].reshape(-1))
-                self.v[o:o + n].copy_(sd["exp_avg_sq"][name].reshape(-1))
-        self.global_step = int(sd.get("global_step", 0))
-        self._micro = int(sd.get("micro", 0))
+        if "param_groups" in sd:
+            flat = [p for g in self._groups for p in g["params"]]
+            n_saved = sum(len(g["params"]) for g in sd["param_groups"])
+            if n_saved != len(flat):
+                raise ValueError(f"optimizer state has {n_saved} parameters, this run trains {len(flat)}")
+            step = 0
+            for i, p in enumerate(flat):
+                st = sd["state"].get(i, sd["state"].get(str(i)))
+                if st is None:
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} != {tuple(p.shape)}")
+                o, n = r.offset[id(p)], p.numel()
+                self.m[o:o + n].copy_(st["exp_avg"].reshape(-1).to(torch.float32))
+                self.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1).to(torch.float32))
+                step = max(step, int(float(st["step"])))
+            self.global_step = step
+            self._micro = step * self.accum
+        else:
+            for p in r.params:
+                o, n, name = r.offset[id(p)], p.numel(), r.names[id(p)]
+                if name in sd["exp_avg"]:
+                    self.m[o:o + n].copy_(sd["exp_avg"][name].reshape(-1))
+                    self.v[o:o + n].copy_(sd["exp_avg_sq"][name].reshape(-1))
+            self.global_step = int(sd.get("global_step", 0))
+            self._micro = int(sd.get("micro", 0))
         bump_weights_epoch()
+
+    @property
+    def scheduler(self):
+        """CosineAnnealingLR-shaped view of the schedule for save_checkpoint / load_checkpoint."""
+        return _SchedulerView(self)
+
+
+class _SchedulerView:
+    def __init__(self, trainer: Trainer):
+        self.t = trainer
+
+    def state_dict(self) -> dict:
+        t = self.t
+        return {"T_max": t.total_steps, "eta_min": float(getattr(t.cfg, "min_lr", 0.0)),
+                "base_lrs": [g["lr"] for g in t._groups], "last_epoch": t.global_step,
+                "_step_count": t.global_step + 1, "_last_lr": [g["lr"] * t.lr_factor(max(t.global_step, 1)) for g in t._groups]}
+
+    def load_state_dict(self, sd: dict):
+        self.t.global_step = int(sd["last_epoch"])
+        self.t._micro = self.t.global_step * self.t.accum

@@ -32,8 +32,9 @@ def checkpoint_path(args, epoch: int, global_step: int) -> str:
 
 def save_checkpoint(args, model, optimizer, scheduler, epoch, global_step, only_save_trainable_params=True,
                     is_master=True) -> Optional[str]:
-    """Rank-0 save.  ``optimizer`` / ``scheduler``: anything with ``state_dict()`` (the Trainer qualifies:
-    fp32 Adam moments of the flat trainable buffer + step), or None."""
+    """Rank-0 save.  ``optimizer`` / ``scheduler``: anything with ``state_dict()``, or None.  A Trainer passes
+    itself and ``trainer.scheduler``: their state dicts have torch.optim.AdamW's / CosineAnnealingLR's layouts, so
+    the file loads into the reference's optimizer and the reference's files load here."""
     if not is_master:
         return None
     path = checkpoint_path(args, epoch, global_step)
@@ -85,12 +86,16 @@ def load_checkpoint(path, model, optimizer=None, scheduler=None, strict=True, ve
     msgs = target.load_state_dict(wanted, strict=strict)
     if len(msgs.unexpected_keys) > 0 and not ignore_nonzero_unexpected_keys:
         raise ValueError(f"unexpected keys found in the model state dict: {path}: {msgs.unexpected_keys}")
+    epoch = int(ckpt["epoch"]) if "epoch" in ckpt else 1
+    global_step = ckpt["global_step"] if "global_step" in ckpt else 1
     for obj, key in ((optimizer, "optimizer"), (scheduler, "scheduler")):
         if obj is not None and ckpt.get(key) is not None:
             try:
                 obj.load_state_dict(ckpt[key])
             except Exception as e:        # the reference only reports this (ref:utils.py:504-514)
                 print(f"failed to load {key} state dict: {e}")
-    epoch = int(ckpt["epoch"]) if "epoch" in ckpt else 1
-    global_step = ckpt["global_step"] if "global_step" in ckpt else 1
+                if hasattr(obj, "global_step"):
+                    # a Trainer whose optimizer state was rejected still resumes the schedule at the
+                    # checkpoint's step (the reference replays its scheduler to global_step, ref:train.py:474-493)
+                    obj.global_step = int(global_step)
     return epoch, global_step
