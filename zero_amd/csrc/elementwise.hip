@@ -375,17 +375,41 @@ struct CvtSegs {
   int nparts[16];       // src holds nparts rows of n values, `stride` elements apart: added in index order
   long long stride[16];
 };
-__global__ __launch_bounds__(256) void f32_to_bf16_multi_kernel(CvtSegs t, float scale) {
+// One block = 64 columns x 16 part groups: thread (c, g) adds parts g, g + 16, ... of its column (4 loads in
+// flight), the 16 group sums meet in LDS and are added in group order: a FIXED tree, so the result is
+// bit-reproducible, without one thread walking hundreds of parts serially.
+__global__ __launch_bounds__(1024) void f32_to_bf16_multi_kernel(CvtSegs t, float scale) {
+  __shared__ float red[16][64];
   const int s = blockIdx.y;
   const float* src = t.src[s];
   bf16_t* dst = t.dst[s];
   const int n = t.n[s], acc = t.accumulate[s], np = t.nparts[s];
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    float v = src[i];
-    for (int p = 1; p < np; ++p) v += src[(size_t)p * t.stride[s] + i];
-    v *= scale;
-    if (acc) v += bf2f(dst[i]);
-    dst[i] = f2bf(v);
+  const long long st = t.stride[s];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  for (int c0 = blockIdx.x * 64; c0 < n; c0 += gridDim.x * 64) {
+    const int i = c0 + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < n) {
+      int p = g;
+      for (; p + 48 < np; p += 64) {
+        a0 += src[(size_t)p * st + i];
+        a1 += src[(size_t)(p + 16) * st + i];
+        a2 += src[(size_t)(p + 32) * st + i];
+        a3 += src[(size_t)(p + 48) * st + i];
+      }
+      for (; p < np; p += 16) a0 += src[(size_t)p * st + i];
+    }
+    red[g][c] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && i < n) {
+      float v = red[0][c];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) v += red[k][c];
+      v *= scale;
+      if (acc) v += bf2f(dst[i]);
+      dst[i] = f2bf(v);
+    }
+    __syncthreads();
   }
 }
 
@@ -528,7 +552,7 @@ extern "C" int zk_f32_to_bf16_multi(const float* const* src, void* const* dst, c
     if (t.nparts[i] < 1 || t.stride[i] < n[j]) return ZK_EINVAL;
     if (n[j] > longest) longest = n[j];
   }
-  hipLaunchKernelGGL(f32_to_bf16_multi_kernel, dim3(grid_for(longest, 64), (unsigned)count), dim3(256), 0, stream, t, scale);
+  hipLaunchKernelGGL(f32_to_bf16_multi_kernel, dim3((unsigned)((longest + 63) / 64 > 64 ? 64 : (longest + 63) / 64), (unsigned)count), dim3(1024), 0, stream, t, scale);
   ZK_CHECK_LAUNCH();
   return ZK_OK;
 }
