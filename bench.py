@@ -234,6 +234,15 @@ def main():
         pr.disable()
         torch.cuda.synchronize()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(28)
+    if rank == 0 and world == 1 and os.environ.get("ZERO_AMD_BENCH_TORCHPROF"):
+        # which Python lines launch the small torch kernels (fills, copies, cats) of a step
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+            step()
+            torch.cuda.synchronize()
+        print(prof.key_averages(group_by_stack_n=6).table(sort_by="self_cuda_time_total", row_limit=60,
+                                                          max_name_column_width=60, max_src_column_width=110),
+              file=sys.stderr)
     t0 = time.perf_counter()
     host_s = 0.0
     for _ in range(args.steps):

@@ -349,6 +349,36 @@ def test_trainer_step_updates_and_accumulates():
         tr.reducer.close()
 
 
+def test_frozen_layout_copies_are_built_once():
+    """The resident transposed copies of FROZEN weights (decoder dgrad, lm_head dgrad, interleaved gate|up) are
+    layout preparation: the first step builds them, later steps build none (a per-step ``weight.detach()`` view
+    used as the cache owner once re-transposed the 788 MB lm_head every step: 4.4 ms of a 65 ms step)."""
+    spec = GOLDEN_CONFIGS["tiny"]
+    enc, dec = spec["enc"], spec["dec"]
+    params = zo.make_params(enc, dec, spec["seed"], surrogate=True)
+    from tests.helpers import build_model, make_cfg
+    from zero_amd import functional as ZF
+    from zero_amd.configs.zero.train_llama import func_optim_filter
+    from zero_amd.methods.engine_ar_instruction_llama import forward_from_ids
+    from zero_amd.train import Trainer
+    cfg = make_cfg(enc, dec, DEV, spec["ft_after"], spec["max_seq_len"])
+    model = build_model(cfg, params)
+    tr = Trainer(cfg, model, forward_from_ids, func_optim_filter(cfg, model), total_steps=10)
+    try:
+        imgs, ids, tgts, img_id, pad_id = zo.synth_batch(enc, dec, **spec["batch"])
+        dimgs = [i.to(DEV).to(torch.bfloat16) for i in imgs]
+        before = ZF.FROZEN_T_BUILDS
+        tr.micro_step(dimgs, ids, tgts, img_id, pad_id)
+        first = ZF.FROZEN_T_BUILDS
+        assert first > before                                  # the frozen surrogate did take the resident-copy path
+        assert "_zk_wt" in model.decoder.lm_head.weight.__dict__   # ... including the lm_head dgrad
+        for _ in range(2):
+            tr.micro_step(dimgs, ids, tgts, img_id, pad_id)
+        assert ZF.FROZEN_T_BUILDS == first
+    finally:
+        tr.reducer.close()
+
+
 def test_nan_loss_is_reported_without_a_per_step_sync():
     """engine:315-316 raises on a NaN loss; here the flag is read back asynchronously (no GPU drain
     between forward and backward) and surfaces at a later check or at flush()."""

@@ -95,6 +95,7 @@ class GradSink:
 # Trainable weights change every step and keep the copy-free transposed-read variant.
 # ------------------------------------------------------------------------------------------
 USE_TRANSPOSED_FROZEN = os.environ.get("ZERO_AMD_DGRAD_T", "1") != "0"
+FROZEN_T_BUILDS = 0      # resident copies built so far (tests: a steady-state step builds none)
 
 
 def _frozen_t(w: torch.Tensor, owner: torch.Tensor) -> torch.Tensor:
@@ -105,6 +106,8 @@ def _frozen_t(w: torch.Tensor, owner: torch.Tensor) -> torch.Tensor:
     hit = cache.get(key)
     if hit is not None and hit[0] == owner._version and hit[1] == w.data_ptr():
         return hit[2]
+    global FROZEN_T_BUILDS
+    FROZEN_T_BUILDS += 1
     wt = w.detach().t().contiguous()          # one-time layout preparation (setup, not the hot path)
     cache[key] = (owner._version, w.data_ptr(), wt)
     return wt
@@ -117,6 +120,8 @@ def _frozen_gate_up(gw: torch.Tensor, uw: torch.Tensor):
     hit = cache.get("gu")
     if (hit is not None and hit[0] == (gw._version, uw._version) and hit[1] == (gw.data_ptr(), uw.data_ptr())):
         return hit[2], hit[3]
+    global FROZEN_T_BUILDS
+    FROZEN_T_BUILDS += 1
     wi = ops.interleave_gate_up(gw.detach(), uw.detach())
     wit = wi.t().contiguous()
     cache["gu"] = ((gw._version, uw._version), (gw.data_ptr(), uw.data_ptr()), wi, wit)
@@ -632,7 +637,11 @@ class LMHeadLossFn(torch.autograd.Function):
     product is only formed for the listed rows.  Returns the fp32 loss sum (0-dim)."""
 
     @staticmethod
-    def forward(ctx, hidden, norm_w, lm_w, rows, labels, inv_rows, eps):
+    def forward(ctx, hidden, norm_w, lm_w, rows, labels, inv_rows, eps, lm_owner=None):
+        # lm_owner: 1-tuple holding the Parameter whose storage ``lm_w`` views (a tuple so autograd does not treat it
+        # as an input).  The resident transposed copy for the dgrad is cached ON that object; a fresh
+        # ``weight.detach()`` view per step would miss the cache and re-transpose 788 MB every step.
+        ctx.lm_owner = lm_owner[0] if lm_owner else None
         B, S, d = hidden.shape
         x2 = hidden.reshape(B * S, d)
         if not x2.is_contiguous():
@@ -658,14 +667,14 @@ class LMHeadLossFn(torch.autograd.Function):
     def backward(ctx, g):
         B, S, d = ctx.shape
         if ctx.empty:
-            return (torch.zeros(ctx.shape, dtype=BF16, device=g.device),) + (None,) * 6
+            return (torch.zeros(ctx.shape, dtype=BF16, device=g.device),) + (None,) * 7
         xs, rstd, dlogits, norm_w, lm_w, inv = ctx.saved_tensors
         g32 = g.reshape(1).to(torch.float32).contiguous()
-        d_hn = dgrad(dlogits, lm_w, alpha_dev=g32)
+        d_hn = dgrad(dlogits, lm_w, owner=ctx.lm_owner, alpha_dev=g32)
         d_xs = ops.rmsnorm_bwd(d_hn, xs, norm_w, rstd)
         # scatter the listed rows back through the inverse map (-1 = no gradient: zero row)
         dx = ops.gather_rows(d_xs, None, inv, d)
-        return (dx.view(B, S, d),) + (None,) * 6
+        return (dx.view(B, S, d),) + (None,) * 7
 
 
 class CrossEntropySumFn(torch.autograd.Function):

@@ -224,7 +224,7 @@ def forward_from_ids(self, cfg, imgs: List[torch.Tensor], input_ids, targets, im
         hidden = dec.model.run_layers(inputs_embeds)
         loss = ZF.LMHeadLossFn.apply(hidden, dec.model.norm.weight.detach(), dec.lm_head.weight.detach(),
                                      dev["rows"], dev["row_labels"], dev["inv_rows"],
-                                     dec.model.norm.variance_epsilon)
+                                     dec.model.norm.variance_epsilon, (dec.lm_head.weight,))
         logits = None
     else:   # any module with the HF call contract (engine:276-280)
         logits = dec(inputs_embeds=inputs_embeds, use_cache=False)["logits"]
