@@ -23,6 +23,18 @@ SHAPES = [  # (name, M, N, K, trans_a, trans_b)
     ("enc wg fc1 TN", 4096, 1024, 4616, True, True),
     ("enc wg qkv TN", 3072, 1024, 4616, True, True),
     ("enc wg o   TN", 1024, 1024, 4616, True, True),
+    ("enc o      NT", 4616, 1024, 1024, False, False),
+    ("ad fc1     NT", 4608, 3072, 1024, False, False),
+    ("ad fc2     NT", 4608, 3072, 3072, False, False),
+    ("c4 qkv     NT", M, 6144, 4096, False, False),
+    ("c4 o       NT", M, 4096, 4096, False, False),
+    ("c4 gateup  NT", M, 28672, 4096, False, False),
+    ("c4 down    NT", M, 4096, 14336, False, False),
+    ("c4 d_down  NT", M, 14336, 4096, False, False),
+    ("c4 d_gu    NT", M, 4096, 28672, False, False),
+    ("c4 d_qkv   NT", M, 4096, 6144, False, False),
+    ("c4 enc qkv NT", 584, 3072, 1024, False, False),
+    ("c4 enc fc1 NT", 584, 4096, 1024, False, False),
     ("lm head    NT", 1024, 128256, 3072, False, False),
     ("lm dgrad   NN", 1024, 3072, 128256, False, True),
     ("square 4k  NT", 4096, 4096, 4096, False, False),
