@@ -114,9 +114,9 @@ def plan_name(plan: int) -> str:
 
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes over this same
-    command (profiles/r01_pmc_summary.json, written by tools/pmc_bench.sh + tools/pmc_summary.py:
+    command (profiles/r02_pmc_summary.json, written by tools/pmc_bench.sh + tools/pmc_summary.py:
     FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None if no summary is present."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     try:
         with open(path) as f:
             ent = json.load(f)["kernels"].get(kernel)
@@ -534,8 +534,8 @@ class _MeanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rows):
         from zero_amd import ops
-        acc = torch.zeros(rows.shape[1], dtype=torch.float32, device=rows.device)
-        ops.colsum_(rows, acc)
+        acc = torch.empty((ops.colsum_parts(rows.shape[0]), rows.shape[1]), dtype=torch.float32, device=rows.device)
+        ops.colsum_(rows, acc)             # per-part partial sums (deterministic), summed below
         ctx.shape = rows.shape
         return acc.sum() / rows.numel()
 
