@@ -6,6 +6,11 @@ from zero_amd import ops
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 SHAPES = [("decoder causal", 8, 768, 24, 8, 128, True), ("encoder bidir ", 8, 577, 16, 16, 64, False)]
+if os.environ.get("ZERO_AMD_ATTN_SWEEP"):     # where the time goes: fixed cost per launch / block vs per tile
+    SHAPES += [("causal S=1536", 8, 1536, 24, 8, 128, True), ("causal S=3072", 4, 3072, 24, 8, 128, True),
+               ("causal S=6144", 2, 6144, 24, 8, 128, True), ("bidir  S=768 ", 8, 768, 24, 8, 128, False),
+               ("bidir  S=3072", 4, 3072, 24, 8, 128, False), ("causal B=32  ", 32, 768, 24, 8, 128, True),
+               ("enc    B=64  ", 64, 577, 16, 16, 64, False), ("enc  S=2308  ", 8, 2308, 16, 16, 64, False)]
 for name, B, S, Hq, Hkv, hd, causal in SHAPES:
     torch.manual_seed(0)
     qkv = torch.randn(B * S, (Hq + 2 * Hkv) * hd, device="cuda").to(torch.bfloat16)
