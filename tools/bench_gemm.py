@@ -47,7 +47,10 @@ SHAPES = [  # (name, M, N, K, trans_a, trans_b)
 
 def main():
     torch.manual_seed(0)
+    only = os.environ.get("ZERO_AMD_GEMM_FILTER")      # comma-separated substrings of shape names
     for name, m, n, k, ta, tb in SHAPES:
+        if only and not any(f in name for f in only.split(",")):
+            continue
         a = torch.randn((k, m) if ta else (m, k), device="cuda").to(torch.bfloat16)
         b = torch.randn((k, n) if tb else (n, k), device="cuda").to(torch.bfloat16)
         out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
