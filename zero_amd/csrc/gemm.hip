@@ -1102,6 +1102,27 @@ void launch_cfg(const GemmArgs& g0, int transA, int transB, hipStream_t stream, 
 #undef ZK_LAUNCH
 }
 
+// Split count of a plain product on the two-stage 128x128 kernel (two 4-wave workgroups per CU = 512 slots), by
+// estimated time in microseconds.  Constants fitted to tools/bench_splitk.py on MI355X (profiles/
+// r02_gemm_splitk_sweep.txt): a K-tile takes a workgroup 1.2 us with a co-resident partner and 0.87 us alone on its
+// CU (k-contiguous operands: x0.56), a workgroup costs 5 us to start and store, the fp32 slabs move 8 bytes per
+// element and split at ~8 TB/s (they stay in the Infinity Cache) and the finishing kernel costs 4 us.
+int splitk_choice(int64_t tiles, int64_t M, int64_t N, int64_t K, bool transposed, int64_t workspace_bytes) {
+  const double tau2 = transposed ? 1.2 : 0.67, tau1 = transposed ? 0.87 : 0.49, fixed = 5.0;
+  int best = 1;
+  double best_cost = 1e300;
+  for (int s_ = 1; s_ <= 16; ++s_) {
+    if (s_ > 1 && (K / s_ < 512 || (int64_t)s_ * M * N * 4 > workspace_bytes)) break;
+    const double kt = (double)((K + s_ - 1) / s_ + BK - 1) / BK;
+    const int64_t blocks = tiles * s_, full = blocks / 512, rem = blocks % 512;
+    double cost = (double)full * (kt * tau2 + fixed);
+    if (rem > 0) cost += kt * ((rem > 256 || full > 0) ? tau2 : tau1) + fixed;
+    if (s_ > 1) cost += (double)s_ * M * N * 8.0 / 8.0e6 + 4.0;
+    if (cost < best_cost) { best_cost = cost; best = s_; }
+  }
+  return best;
+}
+
 // Tile choice: time ~ rounds(tiles / concurrent blocks) x tile area / relative efficiency.
 int choose_tile(int64_t M, int64_t N, int transA, int transB, bool need_tn4, const Plan& P) {
   const bool nt_ring = !transA && !transB && P.ring;
@@ -1196,15 +1217,8 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
   const bool plain = epilogue == ZK_EPI_NONE && !bias && !residual && !aux_out;
   if (plain && workspace && P.splits != 1) {
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    int64_t sp = P.splits > 1 ? P.splits : (tiles <= 300 && K >= 2048 ? 1024 / tiles : 1);
-    if (P.splits <= 1 && tiles > 300 && tiles <= 1024 && K >= 4096) {
-      // mid-size outputs with a long contraction (the adapter's 3072 x 3072 weight gradient: 576 tiles are
-      // 1.125 rounds of the 512 block slots): the smallest split that fills its last round, if the
-      // unsplit grid wastes more than a tenth over it
-      auto eff = [&](int64_t s_) { const double r = (double)(tiles * s_) / 512.0; return r / (double)(int64_t)(r + 0.999999); };
-      for (int64_t s_ = 2; s_ <= 8 && K / s_ >= 1024; ++s_)
-        if (eff(s_) >= 0.88 && eff(s_) > eff(1) + 0.1) { sp = s_; break; }
-    }
+    int64_t sp = P.splits > 1 ? P.splits : 1;
+    if (P.splits <= 1 && tiles <= 1024 && K >= 1024) sp = splitk_choice(tiles, M, N, K, transA || transB, workspace_bytes);
     if (sp > 16) sp = 16;
     while (sp > 1 && (K / sp < 512 || sp * M * N * 4 > workspace_bytes)) --sp;
     if (sp > 1) {
