@@ -975,16 +975,20 @@ __global__ __launch_bounds__(512) void gemm_pring_kernel(GemmArgs g) {
     static_for<TM>([&](auto i_c) {
       constexpr int i = decltype(i_c)::value;
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN / 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fcur[j], fa[i], acc[i][j], 0, 0, 0);
+      if constexpr (SPREAD) {      // mid-row: away from the A refill read at the end of the row
+        __builtin_amdgcn_sched_barrier(0);
+        issue_pieces(std::integral_constant<int, i * NP / TM>{}, std::integral_constant<int, (i + 1) * NP / TM>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = TN / 2; j < TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fcur[j], fa[i], acc[i][j], 0, 0, 0);
       // (scheduling fence: keep the refill BEHIND the MFMAs that read the old value, or the
       //  compiler hoists it into fresh registers and the kernel no longer fits 256 VGPRs)
       __builtin_amdgcn_sched_barrier(0);
       fa[i] = frag_load<false, RS>(na, a_row + i * 16, nkk, lane);
-      if constexpr (SPREAD) {
-        issue_pieces(std::integral_constant<int, i * NP / TM>{}, std::integral_constant<int, (i + 1) * NP / TM>{});
-        __builtin_amdgcn_sched_barrier(0);
-      }
     });
     __builtin_amdgcn_s_setprio(0);
   };
