@@ -358,8 +358,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       }
     }
   }
-  if (qok) {
-    bf16_t* op = a.dq + ((size_t)b * a.S + qi) * a.lddq + head * HD;
+  // dQ leaves through LDS as whole rows (a lane owns 8 bytes of 16 places in one row of the accumulator layout: 32 rows x 16 bytes per store instruction otherwise): the ring is idle once every wave has
+  // passed its last tile; each wave owns a [32][HD] bf16 patch, chunk c of row q at chunk c ^ (q % chunks-per-row)
+  __syncthreads();
+  {
+    unsigned char* ob = smem + wave * (32 * HD * 2);
+    const int ql = lane & 31;
 #pragma unroll
     for (int d = 0; d < C::DB; ++d)
 #pragma unroll
@@ -367,8 +371,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         u32x2 w;
         w[0] = pack2bf(dq[d][4 * r4] * a.scale, dq[d][4 * r4 + 1] * a.scale);
         w[1] = pack2bf(dq[d][4 * r4 + 2] * a.scale, dq[d][4 * r4 + 3] * a.scale);
-        *reinterpret_cast<u32x2*>(op + d * 32 + 8 * r4 + 4 * h) = w;
+        *reinterpret_cast<u32x2*>(ob + ql * (HD * 2) + (((d * 4 + r4) ^ (ql & (C::CPR - 1))) << 4) + 8 * h) = w;
       }
+    constexpr int RPI = 64 / C::CPR;                 // rows per wave-instruction
+    bf16_t* op = a.dq + ((size_t)b * a.S + q0) * a.lddq + head * HD;
+#pragma unroll
+    for (int ps = 0; ps < 32 / RPI; ++ps) {
+      const int row = ps * RPI + lane / C::CPR, ch = lane % C::CPR;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ob + row * (HD * 2) + ((ch ^ (row & (C::CPR - 1))) << 4));
+      if (q0 + row < a.S) *reinterpret_cast<u32x4*>(op + (size_t)row * a.lddq + ch * 8) = v;
+    }
   }
 }
 
@@ -991,7 +1003,7 @@ extern "C" int zk_attn_bwd(const void* q, const void* k, const void* v, const vo
   if (S * ldq * 2 >= 0x7FFFFFF0LL || S * ldo * 2 >= 0x7FFFFFF0LL || S * ldv * 2 >= 0x7FFFFFF0LL || S * ldk * 2 >= 0x7FFFFFF0LL ||
       Hq * S * 4 >= 0x7FFFFFF0LL) return ZK_EINVAL;
   if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(d_o) | reinterpret_cast<uintptr_t>(dk) |
-       reinterpret_cast<uintptr_t>(dv)) & 15) return ZK_EINVAL;
+       reinterpret_cast<uintptr_t>(dv) | reinterpret_cast<uintptr_t>(dq)) & 15) return ZK_EINVAL;
   AttnArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
   a.d_o = (const bf16_t*)d_o; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
