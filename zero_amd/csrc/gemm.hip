@@ -1128,7 +1128,7 @@ int splitk_choice(int64_t tiles, int64_t M, int64_t N, int64_t K, bool transpose
 }
 
 // Tile choice: time ~ rounds(tiles / concurrent blocks) x tile area / relative efficiency.
-int choose_tile(int64_t M, int64_t N, int transA, int transB, bool need_tn4, const Plan& P) {
+int choose_tile(int64_t M, int64_t N, int64_t K, int transA, int transB, bool need_tn4, const Plan& P) {
   const bool nt_ring = !transA && !transB && P.ring;
   if (P.tile >= 0) {
     if (P.tile == 3 && (transB || need_tn4)) return 0;
@@ -1137,8 +1137,14 @@ int choose_tile(int64_t M, int64_t N, int transA, int transB, bool need_tn4, con
   }
   const int bm[5] = {128, 256, 256, 128, 384}, bn[5] = {128, 128, 256, 96, 192};
   const double slots[5] = {512.0, 256.0, 256.0, 512.0, 256.0};   // two 4-wave blocks or one 8-wave block per CU
-  // measured on MI355X (tools/bench_gemm.py); the slot-ring kernels exist for NT products only
-  const double eff[5] = {1.0, 0.9, nt_ring ? 1.2 : 1.02, 0.93, 1.2};
+  // measured on MI355X (tools/bench_gemm.py); the slot-ring kernels exist for NT products only.  The persistent
+  // ring's advantage grows with K (its ring fill and store burst amortise): 1.2 at K <= 2048 (encoder fc1 at
+  // K = 1024 stays on 128x128: 51 us vs 61 us), 1.35 from K = 4096 (the N = 4096 products of the 8B surrogate:
+  // 384 tiles of 256x256 in two rounds beat 1536 tiles of 128x128 in three, 178 vs 190 us at K = 4096, 630 vs 727 us
+  // at K = 14336)
+  const double kf = K <= 2048 ? 0.0 : (K >= 4096 ? 1.0 : (double)(K - 2048) / 2048.0);
+  const double pr = 1.2 + 0.15 * kf;
+  const double eff[5] = {1.0, 0.9, nt_ring ? pr : 1.02, 0.93, pr};
   int best = 0;
   double best_cost = 1e300;
   for (int c = 0; c < 5; ++c) {
@@ -1242,7 +1248,7 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
     ZK_CHECK_LAUNCH();
     return ZK_OK;
   }
-  const int tile = choose_tile(M, N, transA, transB, epilogue == ZK_EPI_SWIGLU, P);
+  const int tile = choose_tile(M, N, K, transA, transB, epilogue == ZK_EPI_SWIGLU, P);
   g_last_plan = tile * 100;            // plain two-stage kernel unless a ring variant takes over below
   switch (tile) {
     case 3: launch_cfg<128, 96, 2, 2>(g, transA, transB, stream, P); break;
