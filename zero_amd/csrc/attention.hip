@@ -37,6 +37,7 @@ struct AttnArgs {
   float* lse;
   const float* lse_in;
   const float* delta;
+  float* delta_out;
   int B, S, Hq, Hkv;
   int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
   float scale;
@@ -246,35 +247,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // =========================================================================================
-// backward: delta = rowsum(dO * O)
-// =========================================================================================
-template <int HD>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* o, const bf16_t* d_o, float* delta, int B, int S,
-                                                         int Hq, int ldo) {
-  constexpr int LPR = HD / 8;  // lanes per (token, head)
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t item = gid / LPR;
-  const int c = (int)(gid % LPR);
-  const int64_t total = (int64_t)B * S * Hq;
-  float acc = 0.f;
-  int64_t tok = 0; int head = 0;
-  if (item < total) {
-    tok = item / Hq; head = (int)(item % Hq);
-    const size_t off = (size_t)tok * ldo + head * HD + c * 8;
-    u32x4 x = *reinterpret_cast<const u32x4*>(o + off);
-    u32x4 y = *reinterpret_cast<const u32x4*>(d_o + off);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc += lo_bf(x[j]) * lo_bf(y[j]) + hi_bf(x[j]) * hi_bf(y[j]);
-  }
-#pragma unroll
-  for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-  if (item < total && c == 0) {
-    int64_t bb = tok / S, s = tok % S;
-    delta[(bb * Hq + head) * S + s] = acc;
-  }
-}
-
-// =========================================================================================
 // backward: dQ  (per 128-query block, sweep over key tiles; same K/V ring as the forward)
 // =========================================================================================
 template <int HD, bool CAUSAL>
@@ -313,7 +285,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   // rows past S: q = dO = 0 gives s = dP = 0, p = 1, dS = 0: harmless, and never stored
   const size_t stat = ((size_t)b * a.Hq + head) * a.S + (qok ? qi : 0);
   const float lse2 = qok ? a.lse_in[stat] * LOG2E : 0.f;
-  const float dlt = qok ? a.delta[stat] : 0.f;
+  // delta = rowsum(dO * O) is formed here (each row belongs to exactly one lane pair of one workgroup) and
+  // written for the dK/dV kernel, which runs after this one: no separate pass over O and dO
+  float dlt = 0.f;
+  {
+    const bf16_t* op_ = a.o + ((size_t)b * a.S + qi) * a.ldo + head * HD + 8 * h;
+#pragma unroll
+    for (int ds = 0; ds < C::DS; ++ds) {
+      const bf16x8 of = gfrag(op_ + ds * 16, qok);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dlt = __builtin_fmaf((float)of[j], (float)dof[ds][j], dlt);
+    }
+    dlt += __shfl_xor(dlt, 32, 64);
+    if (qok && h == 0) a.delta_out[stat] = dlt;
+  }
 
   f32x16 dq[C::DB];
 #pragma unroll
@@ -1007,16 +992,14 @@ extern "C" int zk_attn_bwd(const void* q, const void* k, const void* v, const vo
   AttnArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
   a.d_o = (const bf16_t*)d_o; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
-  a.lse_in = lse; a.delta = delta;
+  a.lse_in = lse; a.delta = delta; a.delta_out = delta;
   a.B = (int)B; a.S = (int)S; a.Hq = (int)Hq; a.Hkv = (int)Hkv;
   a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv; a.ldo = (int)ldo;
   a.lddq = (int)lddq; a.lddk = (int)lddk; a.lddv = (int)lddv; a.scale = scale;
-  const int64_t items = B * S * Hq * (head_dim / 8);
-  dim3 gd((unsigned)((items + 255) / 256)), block(256);
+  dim3 block(256);
   dim3 gq((unsigned)(((S + 127) / 128) * Hq * B));
   dim3 gk((unsigned)(((S + 127) / 128) * Hkv * B)), bk(512);
   if (head_dim == 64) {
-    hipLaunchKernelGGL((attn_delta_kernel<64>), gd, block, 0, stream, a.o, a.d_o, delta, a.B, a.S, a.Hq, a.ldo);
     if (causal) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, block, 0, stream, a);
       hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, true>), gk, bk, 0, stream, a);
@@ -1025,7 +1008,6 @@ extern "C" int zk_attn_bwd(const void* q, const void* k, const void* v, const vo
       hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, false>), gk, bk, 0, stream, a);
     }
   } else {
-    hipLaunchKernelGGL((attn_delta_kernel<128>), gd, block, 0, stream, a.o, a.d_o, delta, a.B, a.S, a.Hq, a.ldo);
     if (causal) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), gq, block, 0, stream, a);
       hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, true>), gk, bk, 0, stream, a);
