@@ -57,7 +57,8 @@ enum {
    * 32j..32j+31, columns [64j+32, 64j+64) the matching up features (the caller interleaves the
    * weight rows once; any K order is fine for the dgrad that follows as long as both operands agree).
    *   ZK_EPI_SWIGLU     : C[M][N = 2F] = interleaved gate|up (saved for backward), and
-   *                       aux_out[M][F] (row stride ldaux) = bf16(silu(gate)) * up.
+   *                       aux_out[M][F] (row stride ldaux) = bf16(silu(gate)) * up.  C may be NULL (this
+   *                       epilogue only): the pre-activations are then not written (no-grad forward).
    *   ZK_EPI_SWIGLU_BWD : the GEMM computes dh[M][N = F]; C[M][2F] (interleaved, row stride ldc) gets
    *                       dgate = dh * up * silu'(gate), dup = dh * silu(gate); aux_in[M][2F] = the
    *                       interleaved gate|up of the forward (row stride ldaux).

@@ -135,6 +135,9 @@ def test_gemm_fused_swiglu_matches_unfused(M, F, K, gemm_tile):
     blk = gu_i.view(M, F // 32, 2, 32)
     assert torch.equal(blk[:, :, 0].reshape(M, F), gu_ref[:, :F]) and torch.equal(blk[:, :, 1].reshape(M, F), gu_ref[:, F:])
     assert torch.equal(h, h_ref)
+    # no-grad forward: the gate|up copy is neither allocated nor written (C = NULL), h is the same
+    none, h2 = ops.gemm_swiglu(x, wi, keep_gu=False)
+    assert none is None and torch.equal(h2, h_ref)
     # backward: dh = dy @ Wd (Wd [D, F]) then SwiGLU'
     D = 72
     dy, wd = rnd(M, D, seed=44), rnd(D, F, seed=45, scale=0.2)

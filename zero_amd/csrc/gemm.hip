@@ -257,7 +257,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, f32x4 (&acc)[TM][T
       u32x4 out;
 #pragma unroll
       for (int e = 0; e < 4; ++e) out[e] = pack2bf(v[2 * e], v[2 * e + 1]);
-      *reinterpret_cast<u32x4*>(cp) = out;
+      if (g.C) *reinterpret_cast<u32x4*>(cp) = out;     // (null C: ZK_EPI_SWIGLU without the gate|up copy)
     }
     if constexpr (TN == 4) {
       if (epi == ZK_EPI_SWIGLU) {
@@ -789,7 +789,7 @@ __device__ __forceinline__ void store_tile_p(const GemmArgs& g, f32x4 (&acc)[TM]
       u32x4 out;
 #pragma unroll
       for (int e = 0; e < 4; ++e) out[e] = pack2bf(v[2 * e], v[2 * e + 1]);
-      *reinterpret_cast<u32x4*>(cp) = out;
+      if (EPI != 2 || g.C) *reinterpret_cast<u32x4*>(cp) = out;   // (null C: ZK_EPI_SWIGLU without the gate|up copy)
       if constexpr (TN == 4 && EPI == 2) {
         // ZK_EPI_SWIGLU: this wave's 64 columns are one interleave block [32 gate | 32 up]: jj = 0
         // delivered the lane's 8 gate features, jj = 1 the matching up features of the same row
@@ -1191,7 +1191,9 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
     if (plan->ablation) return ZK_EINVAL;       // wrong-result timing modes exist in ZK_ABLATION builds only
 #endif
   }
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ZK_EINVAL;
+  // C may be null for ZK_EPI_SWIGLU only: h = silu(gate) * up is still written to aux_out, the interleaved gate|up
+  // pre-activations (needed by the backward alone) are not — inference / no-grad forward saves their 2F bf16 per row
+  if (!A || !B || (!C && epilogue != ZK_EPI_SWIGLU) || M <= 0 || N <= 0 || K <= 0) return ZK_EINVAL;
   if ((N & 7) || (ldc & 7)) return ZK_EINVAL;   // the epilogue moves 8 consecutive n (16 bytes) per lane
   if ((!transA || !transB) && (K & 7)) return ZK_EINVAL;  // k-contiguous operands are read in 8-element chunks
   if (transA ? ((M & 7) || (lda & 7)) : (lda & 7)) return ZK_EINVAL;

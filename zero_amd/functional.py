@@ -474,7 +474,7 @@ class DecoderLayerFn(torch.autograd.Function):
         wgu = packed_rows(gw, uw)
         if fused:
             # gate|up GEMM with the SwiGLU in its epilogue; gu is kept in the interleaved column order
-            gu, hm = ops.gemm_swiglu(h2, _frozen_gate_up(gw, uw)[0])
+            gu, hm = ops.gemm_swiglu(h2, _frozen_gate_up(gw, uw)[0], keep_gu=need)   # (no backward: gu is not written)
         elif wgu is not None:
             gu = ops.gemm(h2, wgu)
             hm = ops.swiglu_fwd(gu, F)

@@ -80,7 +80,7 @@ def layer_infer(layer, x2: torch.Tensor, B: int, S: int, pos0: int, cos_t, sin_t
         # decoding: stream the packed gate|up weight once (GEMV), then the small SwiGLU kernel
         hm = ops.swiglu_fwd(ops.gemm(h2, wgu.detach()), gw.shape[0])
     elif gw.shape[0] % 32 == 0:
-        _, hm = ops.gemm_swiglu(h2, _gate_up_interleaved(gw, uw))
+        _, hm = ops.gemm_swiglu(h2, _gate_up_interleaved(gw, uw), keep_gu=False)   # prefill: h only
     else:
         F = gw.shape[0]
         gu = torch.empty((M, 2 * F), dtype=BF16, device=x2.device)

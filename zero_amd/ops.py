@@ -159,17 +159,18 @@ def interleave_gate_up(gate_w: torch.Tensor, up_w: torch.Tensor) -> torch.Tensor
     return torch.stack((gate_w.reshape(F // 32, 32, K), up_w.reshape(F // 32, 32, K)), dim=1).reshape(2 * F, K).contiguous()
 
 
-def gemm_swiglu(x: torch.Tensor, wgu_i: torch.Tensor):
+def gemm_swiglu(x: torch.Tensor, wgu_i: torch.Tensor, keep_gu: bool = True):
     """gu_i[M, 2F] = x @ wgu_i^T (interleaved gate|up, kept for backward) and h[M, F] = silu(gate) * up,
-    in one launch (ZK_EPI_SWIGLU)."""
+    in one launch (ZK_EPI_SWIGLU).  keep_gu=False (no backward will run): gu_i is neither allocated nor written
+    (returned as None)."""
     _chk2d(x, "x"); _chk2d(wgu_i, "wgu_i")
     M, K = x.shape
     N = wgu_i.shape[0]
     if wgu_i.shape[1] != K or N % 64:
         raise ValueError("gemm_swiglu: shapes")
-    gu = torch.empty((M, N), dtype=BF16, device=x.device)
+    gu = torch.empty((M, N), dtype=BF16, device=x.device) if keep_gu else None
     h = torch.empty((M, N // 2), dtype=BF16, device=x.device)
-    rc = _gemm_call(_p(x), _p(wgu_i), _p(gu), M, N, K, _ld(x), _ld(wgu_i), _ld(gu), 0, 0,
+    rc = _gemm_call(_p(x), _p(wgu_i), _p(gu) if keep_gu else None, M, N, K, _ld(x), _ld(wgu_i), N, 0, 0,
                     EPI_SWIGLU, None, None, 0, _p(h), None, _ld(h), 1.0, None, 0,
                     _workspace(x.device).data_ptr(), WORKSPACE_BYTES)
     check(rc, f"zk_gemm_bf16(SWIGLU) M={M} N={N} K={K}")
