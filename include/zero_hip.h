@@ -88,7 +88,8 @@ int zk_gemv_fused_bf16(const void* x, const void* W, void* y, int64_t M, int64_t
 /* The same product under an explicit kernel plan (no counterpart in the reference: tests exercise every kernel
  * variant through it, benchmarks A/B them).  The library keeps no mutable tuning state: zk_gemm_bf16 is this call
  * with plan = NULL (built-in cost model).  Fields, -1 / 0 = built-in choice unless stated:
- *   tile        -1 cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256, 3 = 128x96, 4 = 384x192 (NT ring only)
+ *   tile        -1 cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256, 3 = 128x96, 4 = 384x192 (NT ring only),
+ *               5 = 192x256 (persistent NT ring, exact shapes only)
  *   splits      0 heuristic, 1 never split K, 2..16 force that many splits (plain products with a workspace)
  *   stage_mode  -1 default (1), 0 LDS-DMA for every operand, 1 registers for transposed operands
  *   ring        -1 default (1), 0 / 1: 3-stage ring kernel for NT products on the 256x128 tile off / on
@@ -111,7 +112,7 @@ int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t M, int64_t 
  * zk_gemm_bf16 call launched, so a benchmark can attribute its event timings to the kernel symbols a
  * profiler reports.  kind * 1000 + tile * 100 + lean * 10 + epilogue class; kind 0 = two-stage
  * gemm_kernel, 1 = gemm_ring_kernel, 2 = gemm_ringx_kernel, 3 = gemm_pring_kernel (persistent),
- * 4 = split-K (4000 + splits); tile 0..4 = 128x128, 256x128, 256x256, 128x96, 384x192. */
+ * 4 = split-K (4000 + splits); tile 0..5 = 128x128, 256x128, 256x256, 128x96, 384x192, 192x256. */
 int zk_gemm_last_plan(void);
 
 /* ---- fused attention ----------------------------------------------------------------

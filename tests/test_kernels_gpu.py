@@ -183,6 +183,40 @@ def test_gemm_persistent_ring(M, N, K, tile):
         ops.set_gemm_tile(-1)
 
 
+@pytest.mark.parametrize("M,N,K", [(6144, 4096, 512), (1536, 2048, 320), (6144, 14336, 256)])
+def test_gemm_persistent_ring_192x256(M, N, K):
+    """The 192x256 tile of the persistent ring (two K-tiles of 7 x 64-row slots: a wave's rows span slots):
+    taken for exact shapes, BIT-equal to the 256x256 ring for every epilogue class, repeatable."""
+    a, b = rnd(M, K, seed=57), rnd(N, K, seed=58, scale=0.5)
+    bias, res = rnd(N, seed=59), rnd(M, N, seed=60)
+    F = N // 2
+    wd_t, gu = rnd(F, K, seed=64, scale=0.2), rnd(M, 2 * F, seed=65)
+    try:
+        outs = {}
+        for tile in (5, 2):
+            ops.set_gemm_tile(tile)
+            c0 = ops.gemm(a, b)
+            assert ops.lib.zk_gemm_last_plan() // 100 == 30 + tile       # persistent ring on the requested tile
+            c1 = ops.gemm(a, b, bias=bias, residual=res)
+            aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            c2 = ops.gemm(a, b, bias=bias, epilogue=ops.EPI_QUICK_GELU, aux_out=aux)
+            c3 = ops.gemm(a, b, out=res.clone(), accumulate=True)
+            gu_i, h = ops.gemm_swiglu(a, b)
+            dgu = ops.gemm_swiglu_bwd(a, wd_t, gu)
+            outs[tile] = (c0, c1, aux, c2, c3, gu_i, h, dgu)
+        assert relerr(outs[5][0], a.float() @ b.float().t()) < 6e-3
+        for x, y in zip(outs[5], outs[2]):
+            assert torch.equal(x, y)
+        ops.set_gemm_tile(5)
+        for _ in range(5):
+            assert torch.equal(ops.gemm(a, b), outs[5][0])
+        ops.set_gemm_tile(5)
+        ragged = ops.gemm(a[: M - 8], b)                                  # not a multiple of 192: falls back to 256x256
+        assert ops.lib.zk_gemm_last_plan() // 100 == 32 and torch.equal(ragged, outs[2][0][: M - 8])
+    finally:
+        ops.set_gemm_tile(-1)
+
+
 def test_gemm_persistent_ring_repeatable():
     """Same launch 20 times: a read that overtakes its DMA (or a slot refilled too early) shows up as
     run-to-run differences; also against the fp32 product at the decoder's gate|up shape."""

@@ -6,4 +6,4 @@ for l in open(sys.argv[1]):
     name = l[:14]
     f = dict(re.findall(r"(t ?-?\d[pr]|nosplit):\s+[\d.]+ TF \(\s*(\d+) us\)", l))
     if f:
-        print(name, " ".join(f"{k.replace(' ', '')}={v}" for k, v in f.items() if k.replace(' ', '') in ("t0p", "t3p", "t-1p", "nosplit")))
+        print(name, " ".join(f"{k.replace(' ', '')}={v}" for k, v in f.items() if k.replace(' ', '') in ("t0p", "t2p", "t3p", "t4p", "t5p", "t-1p", "nosplit")))

@@ -55,8 +55,8 @@ def main():
         b = torch.randn((k, n) if tb else (n, k), device="cuda").to(torch.bfloat16)
         out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
         line = f"{name}  M={m:6d} N={n:6d} K={k:6d} :"
-        for cfg, stg, pr in ((0, 11, 1), (1, 11, 1), (2, 11, 0), (2, 11, 1), (3, 11, 1), (4, 11, 0), (4, 11, 1), (-1, 11, 1)):
-            if (stg == 22 or cfg == 4 or pr == 0) and (ta or tb):
+        for cfg, stg, pr in ((0, 11, 1), (1, 11, 1), (2, 11, 0), (2, 11, 1), (3, 11, 1), (4, 11, 0), (4, 11, 1), (5, 11, 1), (-1, 11, 1)):
+            if (stg == 22 or cfg in (4, 5) or pr == 0) and (ta or tb):
                 continue
             ops.set_gemm_tile(21)
             ops.set_gemm_tile(stg)

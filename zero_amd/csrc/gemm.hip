@@ -823,7 +823,11 @@ __global__ __launch_bounds__(512) void gemm_pring_kernel(GemmArgs g) {
   constexpr int TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
   constexpr int SA = BM / RS, SB = BN / RS, SPT = SA + SB;
   static_assert(SA * RS == BM && SB * RS == BN && NSLOT >= 2 * SPT && NSLOT - 2 * SPT < SPT, "slot geometry");
-  static_assert(RS % (TM * 16) == 0 && RS % (TN * 16) == 0, "a wave's rows lie in one slot");
+  // With exactly two K-tiles in the ring a K-tile never wraps: its slots are one linear [BM + BN][64] image and a
+  // wave's rows may span slots (192x256: 7 slots of 64 rows per K-tile); otherwise they must lie in one slot.
+  constexpr bool LINEAR = NSLOT == 2 * SPT;
+  static_assert(LINEAR || (RS % (TM * 16) == 0 && RS % (TN * 16) == 0), "a wave's rows lie in one slot");
+  static_assert(RS % 16 == 0, "a fragment's rows lie in one slot");
   constexpr int SLOT = RS * BK * 2;
   constexpr int PER = RS * 8 / NT;             // DMA instructions per thread per slot
   static_assert(PER * NT == RS * 8, "slot rows");
@@ -937,25 +941,17 @@ __global__ __launch_bounds__(512) void gemm_pring_kernel(GemmArgs g) {
   };
   auto issue_group = [&](auto first_c, auto count_c) {
     constexpr int FIRST = decltype(first_c)::value, COUNT = decltype(count_c)::value;
-    static_assert(COUNT <= 9, "unrolled by hand");
-    if constexpr (COUNT > 0) issue_part(std::integral_constant<int, (FIRST + 0) % SPT>{});
-    if constexpr (COUNT > 1) issue_part(std::integral_constant<int, (FIRST + 1) % SPT>{});
-    if constexpr (COUNT > 2) issue_part(std::integral_constant<int, (FIRST + 2) % SPT>{});
-    if constexpr (COUNT > 3) issue_part(std::integral_constant<int, (FIRST + 3) % SPT>{});
-    if constexpr (COUNT > 4) issue_part(std::integral_constant<int, (FIRST + 4) % SPT>{});
-    if constexpr (COUNT > 5) issue_part(std::integral_constant<int, (FIRST + 5) % SPT>{});
-    if constexpr (COUNT > 6) issue_part(std::integral_constant<int, (FIRST + 6) % SPT>{});
-    if constexpr (COUNT > 7) issue_part(std::integral_constant<int, (FIRST + 7) % SPT>{});
-    if constexpr (COUNT > 8) issue_part(std::integral_constant<int, (FIRST + 8) % SPT>{});
+    static_for<COUNT>([&](auto k_c) { issue_part(std::integral_constant<int, (FIRST + decltype(k_c)::value) % SPT>{}); });
   };
+
   // prologue: fill the ring (host guarantees nk >= 4: no tile boundary in here), wait for K-tile 0
   issue_group(std::integral_constant<int, 0>{}, std::integral_constant<int, NSLOT>{});
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - SPT) * PER) : "memory");
   __builtin_amdgcn_s_barrier();
 
   // ---- consume side
-  const int a_part = wm * (TM * 16) / RS, a_row = wm * (TM * 16) - a_part * RS;
-  const int b_part = SA + wn * (TN * 16) / RS, b_row = wn * (TN * 16) % RS;
+  const int a_part = LINEAR ? 0 : wm * (TM * 16) / RS, a_row = wm * (TM * 16) - a_part * RS;
+  const int b_part = LINEAR ? SA : SA + wn * (TN * 16) / RS, b_row = LINEAR ? wn * (TN * 16) : wn * (TN * 16) % RS;
   int c_pos = 0;                                // ring position of part 0 of the K-tile being multiplied
   auto slot_of = [&](int pos0, int part) {
     int p = pos0 + part;
@@ -1133,10 +1129,11 @@ int choose_tile(int64_t M, int64_t N, int64_t K, int transA, int transB, bool ne
   if (P.tile >= 0) {
     if (P.tile == 3 && (transB || need_tn4)) return 0;
     if (P.tile == 4 && (!nt_ring || need_tn4)) return 2;
+    if (P.tile == 5 && !(nt_ring && P.pring && M % 192 == 0 && N % 256 == 0 && K % BK == 0 && K >= 4 * BK)) return 2;
     return P.tile;
   }
-  const int bm[5] = {128, 256, 256, 128, 384}, bn[5] = {128, 128, 256, 96, 192};
-  const double slots[5] = {512.0, 256.0, 256.0, 512.0, 256.0};   // two 4-wave blocks or one 8-wave block per CU
+  const int bm[6] = {128, 256, 256, 128, 384, 192}, bn[6] = {128, 128, 256, 96, 192, 256};
+  const double slots[6] = {512.0, 256.0, 256.0, 512.0, 256.0, 256.0};   // two 4-wave blocks or one 8-wave block per CU
   // measured on MI355X (tools/bench_gemm.py); the slot-ring kernels exist for NT products only.  The persistent
   // ring's advantage grows with K (its ring fill and store burst amortise): 1.2 at K <= 2048 (encoder fc1 at
   // K = 1024 stays on 128x128: 51 us vs 61 us), 1.35 from K = 4096 (the N = 4096 products of the 8B surrogate:
@@ -1144,11 +1141,14 @@ int choose_tile(int64_t M, int64_t N, int64_t K, int transA, int transB, bool ne
   // at K = 14336)
   const double kf = K <= 2048 ? 0.0 : (K >= 4096 ? 1.0 : (double)(K - 2048) / 2048.0);
   const double pr = 1.2 + 0.15 * kf;
-  const double eff[5] = {1.0, 0.9, nt_ring ? pr : 1.02, 0.93, pr};
+  // 192x256 (persistent ring, exact shapes only): 9.1 B/kFLOP of operand traffic against 7.8 — it wins where it
+  // removes a partial round (M = 6144, N = 4096: 512 tiles = two per CU, against 384 tiles of 256x256 = 1.5)
+  const bool t5 = nt_ring && P.pring && M % 192 == 0 && N % 256 == 0 && K % BK == 0 && K >= 4 * BK;
+  const double eff[6] = {1.0, 0.9, nt_ring ? pr : 1.02, 0.93, pr, pr * 0.94};
   int best = 0;
   double best_cost = 1e300;
-  for (int c = 0; c < 5; ++c) {
-    if ((c == 3 && transB) || (c == 4 && !nt_ring)) continue;
+  for (int c = 0; c < 6; ++c) {
+    if ((c == 3 && transB) || (c == 4 && !nt_ring) || (c == 5 && !t5)) continue;
     if (need_tn4 && (c == 3 || c == 4)) continue;   // the SwiGLU epilogue needs 64 columns per wave
     double tiles = (double)((M + bm[c] - 1) / bm[c]) * (double)((N + bn[c] - 1) / bn[c]);
     double rounds = (double)(int64_t)((tiles + slots[c] - 1) / slots[c]);
@@ -1177,7 +1177,7 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
                                  int64_t workspace_bytes, const zk_gemm_plan_t* plan, hipStream_t stream) {
   Plan P;
   if (plan) {
-    if (plan->tile < -1 || plan->tile > 4 || plan->splits < 0 || plan->splits > 16 || plan->band < 0 || plan->band > 16)
+    if (plan->tile < -1 || plan->tile > 5 || plan->splits < 0 || plan->splits > 16 || plan->band < 0 || plan->band > 16)
       return ZK_EINVAL;
     P.tile = plan->tile; P.splits = plan->splits;
     if (plan->stage_mode >= 0) P.stage_mode = plan->stage_mode != 0;
@@ -1254,11 +1254,12 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
   g_last_plan = tile * 100;            // plain two-stage kernel unless a ring variant takes over below
   switch (tile) {
     case 3: launch_cfg<128, 96, 2, 2>(g, transA, transB, stream, P); break;
+    case 5:
     case 4:
     case 2: {
       if (!transA && !transB && P.ring) {
         GemmArgs gr = g;
-        const int bm = tile == 4 ? 384 : 256, bn = tile == 4 ? 192 : 256;
+        const int bm = tile == 4 ? 384 : (tile == 5 ? 192 : 256), bn = tile == 4 ? 192 : 256;
         gr.tiles_m = (g.M + bm - 1) / bm; gr.tiles_n = (g.N + bn - 1) / bn;
         const dim3 rg(gr.tiles_m * gr.tiles_n);
         const bool lean = g.M % bm == 0 && g.N % bn == 0 && g.K % BK == 0 && P.lean;
@@ -1286,7 +1287,8 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
           gr.phase_delay = P.phase_delay >= 0 ? P.phase_delay : (ntl >= 3 * ncu ? 300 : 0);
 #define ZK_PRING(EPI_) \
   do { \
-    if (tile == 4 && lean) hipLaunchKernelGGL((gemm_pring_kernel<384, 192, 4, 2, 192, 6, true, EPI_>), pg, dim3(512), 0, stream, gr); \
+    if (tile == 5) hipLaunchKernelGGL((gemm_pring_kernel<192, 256, 2, 4, 64, 14, true, EPI_>), pg, dim3(512), 0, stream, gr); \
+    else if (tile == 4 && lean) hipLaunchKernelGGL((gemm_pring_kernel<384, 192, 4, 2, 192, 6, true, EPI_>), pg, dim3(512), 0, stream, gr); \
     else if (tile == 4) hipLaunchKernelGGL((gemm_pring_kernel<384, 192, 4, 2, 192, 6, false, EPI_>), pg, dim3(512), 0, stream, gr); \
     else if (lean) hipLaunchKernelGGL((gemm_pring_kernel<256, 256, 2, 4, 128, 9, true, EPI_>), pg, dim3(512), 0, stream, gr); \
     else hipLaunchKernelGGL((gemm_pring_kernel<256, 256, 2, 4, 128, 9, false, EPI_>), pg, dim3(512), 0, stream, gr); \
@@ -1298,6 +1300,7 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
 #undef ZK_PRING
           break;
         }
+        if (tile == 5) return ZK_EINVAL;   // (choose_tile only returns 5 when the persistent ring's conditions hold)
         g_last_plan = 2000 + tile * 100 + (lean ? 10 : 0);
 #define ZK_RINGX(MODE_) \
   do { \

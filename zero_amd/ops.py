@@ -486,7 +486,7 @@ def f32_to_bf16_multi_(pairs, scale: float = 1.0):
 
 def set_gemm_tile(cfg: int = -1):
     """Test / tool hook: edit the per-call kernel plan that ops.gemm passes to zk_gemm_bf16_plan (the numeric
-    codes are kept from the round-1 tools).  -1 / 0..4 tile (cost model, 128x128, 256x128, 256x256, 128x96,
+    codes are kept from the round-1 tools).  -1 / 0..5 tile (cost model, 128x128, 256x128, 256x256, 128x96,
     384x192); 10 / 11 staging mode; 20 / 21 256x128 ring off / on; 30..33 ablation mode (needs a -DZK_ABLATION
     build); 40 / 41 lean addressing; 50 / 51 persistent ring off / on; 60 + b band; 100 split-K heuristic,
     101 no split-K, 102..116 forced splits; 100000 + t start stagger, 99999 built-in stagger.  When every field
@@ -512,7 +512,7 @@ def set_gemm_tile(cfg: int = -1):
         pl.phase_delay = -1
     elif 100 <= cfg <= 116:
         pl.splits = cfg - 100
-    elif -1 <= cfg <= 4:
+    elif -1 <= cfg <= 5:
         pl.tile = cfg
     else:
         raise ValueError(f"set_gemm_tile: unknown code {cfg}")
