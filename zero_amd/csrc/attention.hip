@@ -102,7 +102,7 @@ struct KvRing {
   static constexpr int RB = HD * 2;
   static constexpr int TILE = KV * RB;
   static constexpr int STAGE = 2 * TILE;
-  static constexpr int NST = HD == 128 ? 2 : 4;            // 64 KiB per block either way
+  static constexpr int NST = HD == 128 ? 2 : 3;            // 64 KiB (hd 128) / 48 KiB (hd 64: three blocks per CU)
   static constexpr int NQ = KV * (HD / 8) / 256;           // 16-byte DMA instructions per thread per operand tile
   static constexpr int PER = 2 * NQ;
 
@@ -131,7 +131,7 @@ struct KvRing {
 };
 
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_fwd_kernel(AttnArgs a) {
   using C = Cfg<HD>;
   using R = KvRing<HD>;
   constexpr int KV = R::KV;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 // backward: dQ  (per 128-query block, sweep over key tiles; same K/V ring as the forward)
 // =========================================================================================
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(AttnArgs a) {
   using C = Cfg<HD>;
   using R = KvRing<HD>;
   constexpr int KV = R::KV;
