@@ -94,7 +94,7 @@ def flops_per_image(enc_layers, ft_after, d, nh, nkv, f, Ld, V, S, T=577, D=1024
     return total
 
 
-_TILES = {0: "128,128", 1: "256,128", 2: "256,256", 3: "128,96", 4: "384,192"}
+_TILES = {0: "128,128", 1: "256,128", 2: "256,256", 3: "128,96", 4: "384,192", 5: "192,256"}
 
 
 def plan_name(plan: int) -> str:
