@@ -112,7 +112,9 @@ int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t M, int64_t 
  * zk_gemm_bf16 call launched, so a benchmark can attribute its event timings to the kernel symbols a
  * profiler reports.  kind * 1000 + tile * 100 + lean * 10 + epilogue class; kind 0 = two-stage
  * gemm_kernel, 1 = gemm_ring_kernel, 2 = gemm_ringx_kernel, 3 = gemm_pring_kernel (persistent),
- * 4 = split-K (4000 + splits); tile 0..5 = 128x128, 256x128, 256x256, 128x96, 384x192, 192x256. */
+ * 4 = split-K (4000 + splits); tile 0..5 = 128x128, 256x128, 256x256, 128x96, 384x192, 192x256; epilogue
+ * class of the persistent kernel: 0 plain / bias / residual / accumulate, 1 quick-GELU pair, 2 SwiGLU pair,
+ * 4 erf-GELU pair. */
 int zk_gemm_last_plan(void);
 
 /* ---- fused attention ----------------------------------------------------------------

@@ -173,7 +173,9 @@ def test_gemm_persistent_ring(M, N, K, tile):
             c2 = ops.gemm(a, b, bias=bias, epilogue=ops.EPI_QUICK_GELU, aux_out=aux)
             c3 = ops.gemm(a, b, epilogue=ops.EPI_MUL_DGELU_ERF, aux_in=res, alpha=0.5)
             c4 = ops.gemm(a, b, out=res.clone(), accumulate=True)
-            outs[pr] = (c0, c1, aux, c2, c3, c4)
+            aux5 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            c5 = ops.gemm(a, b, bias=bias, epilogue=ops.EPI_GELU_ERF, aux_out=aux5)      # the adapter's epilogue pair
+            outs[pr] = (c0, c1, aux, c2, c3, c4, aux5, c5)
         ref = a.float() @ b.float().t()
         assert relerr(outs[51][0], ref) < 6e-3
         for x, y in zip(outs[51], outs[50]):

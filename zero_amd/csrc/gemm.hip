@@ -706,7 +706,7 @@ __device__ __forceinline__ void store_tile_p(const GemmArgs& g, f32x4 (&acc)[TM]
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[jj][e] = 0.f;
     const int n = nw + jj * 32 + rq * 8;
-    if (EPI < 2 && g.bias && n < g.N) {
+    if ((EPI < 2 || EPI == 4) && g.bias && n < g.N) {
       const u32x4 b = *reinterpret_cast<const u32x4*>(g.bias + n);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { bias[jj][2 * e] = lo_bf(b[e]); bias[jj][2 * e + 1] = hi_bf(b[e]); }
@@ -759,29 +759,35 @@ __device__ __forceinline__ void store_tile_p(const GemmArgs& g, f32x4 (&acc)[TM]
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha + bias[jj][e];
-      if (EPI == 1 && ok) {
-        if (epi == ZK_EPI_QUICK_GELU) {
+      if ((EPI == 1 || EPI == 4) && ok) {      // 1: the quick-GELU pair, 4: the erf-GELU pair (adapter)
+        if (epi == ZK_EPI_QUICK_GELU || epi == ZK_EPI_GELU_ERF) {
           u32x4 pre;
 #pragma unroll
           for (int e = 0; e < 4; ++e) pre[e] = pack2bf(v[2 * e], v[2 * e + 1]);
           if (g.aux_out) *reinterpret_cast<u32x4*>(g.aux_out + (size_t)m * g.ldc + n) = pre;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[2 * e] = act_quick_gelu(lo_bf(pre[e])); v[2 * e + 1] = act_quick_gelu(hi_bf(pre[e])); }
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] = EPI == 1 ? act_quick_gelu(lo_bf(pre[e])) : act_gelu_erf(lo_bf(pre[e]));
+            v[2 * e + 1] = EPI == 1 ? act_quick_gelu(hi_bf(pre[e])) : act_gelu_erf(hi_bf(pre[e]));
+          }
         } else {
           const u32x4 h = *reinterpret_cast<const u32x4*>(g.aux_in + (size_t)m * g.ldaux + n);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= dact_quick_gelu((e & 1) ? hi_bf(h[e >> 1]) : lo_bf(h[e >> 1]));
+          for (int e = 0; e < 8; ++e) {
+            const float x = (e & 1) ? hi_bf(h[e >> 1]) : lo_bf(h[e >> 1]);
+            v[e] *= EPI == 1 ? dact_quick_gelu(x) : dact_gelu_erf(x);
+          }
         }
       }
       if (!ok) continue;
-      if (EPI < 2 && g.residual) {
+      if ((EPI < 2 || EPI == 4) && g.residual) {
         // x = residual + bf16(f(x)) : the branch output is rounded before the add
         const u32x4 r = *reinterpret_cast<const u32x4*>(g.residual + (size_t)m * g.ldr + n);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e])) + ((e & 1) ? hi_bf(r[e >> 1]) : lo_bf(r[e >> 1]));
       }
       bf16_t* cp = g.C + (size_t)m * g.ldc + n;
-      if (EPI < 2 && g.accumulate) {
+      if ((EPI < 2 || EPI == 4) && g.accumulate) {
         const u32x4 o = *reinterpret_cast<const u32x4*>(cp);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += (e & 1) ? hi_bf(o[e >> 1]) : lo_bf(o[e >> 1]);
@@ -1263,12 +1269,12 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
         gr.tiles_m = (g.M + bm - 1) / bm; gr.tiles_n = (g.N + bn - 1) / bn;
         const dim3 rg(gr.tiles_m * gr.tiles_n);
         const bool lean = g.M % bm == 0 && g.N % bn == 0 && g.K % BK == 0 && P.lean;
-        // persistent ring: needs >= 4 K-tiles per tile and whole-matrix 32-bit byte offsets; the
-        // erf-GELU epilogues (adapter only) stay on the one-tile-per-workgroup kernel
+        // persistent ring: needs >= 4 K-tiles per tile and whole-matrix 32-bit byte offsets
         const int pclass = P.ring_mode == 3 ? 3
                            : epilogue == ZK_EPI_NONE ? 0
                            : (epilogue == ZK_EPI_QUICK_GELU || epilogue == ZK_EPI_MUL_DQUICK_GELU) ? 1
-                           : (epilogue == ZK_EPI_SWIGLU || epilogue == ZK_EPI_SWIGLU_BWD) ? 2 : -1;
+                           : (epilogue == ZK_EPI_SWIGLU || epilogue == ZK_EPI_SWIGLU_BWD) ? 2
+                           : (epilogue == ZK_EPI_GELU_ERF || epilogue == ZK_EPI_MUL_DGELU_ERF) ? 4 : -1;
         if (P.pring && pclass >= 0 && (g.K + BK - 1) / BK >= 4 && (M + 64) * lda * 2 < 0x7FFFFFF0LL &&
             (N + 64) * ldb * 2 < 0x7FFFFFF0LL && (P.ring_mode == 0 || P.ring_mode == 3)) {
           const int ncu = num_cus();
@@ -1296,6 +1302,7 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
           if (pclass == 0) ZK_PRING(0);
           else if (pclass == 1) ZK_PRING(1);
           else if (pclass == 2) ZK_PRING(2);
+          else if (pclass == 4) ZK_PRING(4);
           else ZK_PRING(3);
 #undef ZK_PRING
           break;
