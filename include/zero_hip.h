@@ -275,6 +275,12 @@ int zk_embed_finish(const void* patch, const void* cls, const void* pos, void* o
  * (row of the image-embedding block).  Rows are D bf16.  gather_rows_add: dst[r] += ...
  * is used for the backward scatter through the inverse map.
  */
+/* dst[C][R] (row stride ld_dst) = transpose of src[R][C] (row stride ld_src); R, C multiples of 8.  Replaces
+ * `weight.t().contiguous()` (ATen strided copy) where a k-contiguous copy of a weight is prepared for the dgrad
+ * GEMMs (no counterpart in the reference: it reads W through F.linear's backward). */
+int zk_transpose_bf16(const void* src, void* dst, int64_t R, int64_t C, int64_t ld_src, int64_t ld_dst,
+                      hipStream_t stream);
+
 int zk_gather_rows(const void* table0, const void* table1, const int32_t* codes, void* dst,
                    int64_t rows, int64_t D, int accumulate, hipStream_t stream);
 

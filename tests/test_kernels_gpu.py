@@ -599,3 +599,14 @@ def test_sumsq_adamw_f32tobf16():
     d0 = dst.clone()
     ops.f32_to_bf16_(src, dst, scale=0.5, accumulate=True)
     assert relerr(dst, d0.float() + 0.5 * src) < 6e-3
+
+
+@pytest.mark.parametrize("R,C", [(1024, 4096), (3072, 1024), (136, 72), (8, 8), (4096, 1000)])
+def test_transpose(R, C):
+    """zk_transpose_bf16: bit-exact, contiguous and row-strided sources (a packed q|k|v view)."""
+    w = rnd(R, C, seed=71)
+    assert torch.equal(ops.transpose(w), w.t().contiguous())
+    big = rnd(R, C + 24, seed=72)
+    view = big[:, 8:8 + C]
+    assert torch.equal(ops.transpose(view), view.t().contiguous())
+

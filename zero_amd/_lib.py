@@ -48,6 +48,7 @@ SIGNATURES = {
     "zk_act_bwd": [_P, _P, _P, _L, _I, _P],
     "zk_patch_im2col": [_P, _P, _L, _L, _L, _L, _L, _P],
     "zk_embed_finish": [_P, _P, _P, _P, _L, _L, _L, _P],
+    "zk_transpose_bf16": [_P, _P, _L, _L, _L, _L, _P],
     "zk_gather_rows": [_P, _P, _P, _P, _L, _L, _I, _P],
     "zk_cross_entropy": [_P, _P, _P, _P, _P, _L, _L, _L, _P],
     "zk_sumsq": [_P, _P, _P, _L, _F, _P],

@@ -488,6 +488,46 @@ extern "C" int zk_embed_finish(const void* patch, const void* cls, const void* p
   return ZK_OK;
 }
 
+// dst[c][r] = src[r][c]: 64 x 64 tiles through LDS (rows padded to 66 elements: the column reads of the second
+// phase step 33 dwords, an odd stride, across the banks), 16-byte global loads, 8-byte global stores.  Layout
+// preparation for the k-contiguous GEMM variant: the trainable weights are transposed once per optimizer step
+// (ATen's strided copy moves ~0.4 TB/s here; this kernel is HBM-rate).
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* src, bf16_t* dst, int R, int C, int lds_, int ldd) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {              // 64 rows x 8 chunks of 8 elements = 512 chunks, two per thread
+    const int idx = t + 256 * i, r = idx >> 3, ch = idx & 7;
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (r0 + r < R && c0 + ch * 8 < C) v = *reinterpret_cast<const u32x4*>(src + (size_t)(r0 + r) * lds_ + c0 + ch * 8);
+    unsigned int* p = reinterpret_cast<unsigned int*>(&tile[r][ch * 8]);
+    p[0] = v[0]; p[1] = v[1]; p[2] = v[2]; p[3] = v[3];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {              // 64 output rows (= source columns) x 16 chunks of 4 elements
+    const int idx = t + 256 * i, c = idx >> 4, q = idx & 15;
+    if (c0 + c < C && r0 + q * 4 < R) {
+      u32x2 o;
+      o[0] = (unsigned int)tile[q * 4][c] | ((unsigned int)tile[q * 4 + 1][c] << 16);
+      o[1] = (unsigned int)tile[q * 4 + 2][c] | ((unsigned int)tile[q * 4 + 3][c] << 16);
+      *reinterpret_cast<u32x2*>(dst + (size_t)(c0 + c) * ldd + r0 + q * 4) = o;
+    }
+  }
+}
+
+extern "C" int zk_transpose_bf16(const void* src, void* dst, int64_t R, int64_t C, int64_t ld_src, int64_t ld_dst,
+                                 hipStream_t stream) {
+  if (!src || !dst || R <= 0 || C <= 0 || (R & 7) || (C & 7) || (ld_src & 7) || (ld_dst & 7) || ld_src < C || ld_dst < R)
+    return ZK_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) return ZK_EINVAL;
+  if ((C + 63) / 64 > 0x7FFFFFFF || (R + 63) / 64 > 65535) return ZK_EINVAL;
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64)), dim3(256), 0, stream,
+                     (const bf16_t*)src, (bf16_t*)dst, (int)R, (int)C, (int)ld_src, (int)ld_dst);
+  ZK_CHECK_LAUNCH();
+  return ZK_OK;
+}
+
 extern "C" int zk_gather_rows(const void* table0, const void* table1, const int32_t* codes, void* dst, int64_t rows,
                               int64_t D, int accumulate, hipStream_t stream) {
   if (!codes || !dst || rows <= 0 || D <= 0 || (D & 7)) return ZK_EINVAL;

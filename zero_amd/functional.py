@@ -98,6 +98,13 @@ USE_TRANSPOSED_FROZEN = os.environ.get("ZERO_AMD_DGRAD_T", "1") != "0"
 FROZEN_T_BUILDS = 0      # resident copies built so far (tests: a steady-state step builds none)
 
 
+def _transposed(w: torch.Tensor) -> torch.Tensor:
+    """[in, out] copy of an [out, in] weight: zk_transpose_bf16 (HBM rate) where it applies, ATen otherwise."""
+    if w.is_cuda and w.dtype == BF16 and w.dim() == 2 and w.stride(1) == 1 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
+        return ops.transpose(w)
+    return w.t().contiguous()
+
+
 def _frozen_t(w: torch.Tensor, owner: torch.Tensor) -> torch.Tensor:
     """The copy lives on the owning Parameter object (not in a global table keyed by address:
     a freed model's addresses get reused), and is rebuilt if the weights were written to."""
@@ -108,7 +115,7 @@ def _frozen_t(w: torch.Tensor, owner: torch.Tensor) -> torch.Tensor:
         return hit[2]
     global FROZEN_T_BUILDS
     FROZEN_T_BUILDS += 1
-    wt = w.detach().t().contiguous()          # one-time layout preparation (setup, not the hot path)
+    wt = _transposed(w.detach())              # one-time layout preparation (setup, not the hot path)
     cache[key] = (owner._version, w.data_ptr(), wt)
     return wt
 
@@ -144,12 +151,13 @@ def dgrad(dy2d: torch.Tensor, w: torch.Tensor, owner: Optional[torch.Tensor] = N
 # dgrad through TRAINABLE weights with many rows (C2: 64 x 577 = 36928 tokens): transposing the weight once
 # per optimizer step (8-34 MB of byte traffic per encoder layer) lets dx = dy W run as the NT product on the
 # persistent-ring kernel (~1.0 PF) instead of the transposed-LDS-read kernel (~0.5 PF, tools/bench_enc_gemm.py).
-# Below ~8k rows the products are too small for the copies to pay (C3's encoder, M = 4616, keeps the copy-free
-# path).  The copy is keyed on (weights epoch, tensor version, address): the Trainer's fused AdamW writes the
+# With ATen's strided copy (~0.4 TB/s) the copies only paid from ~8k rows; zk_transpose_bf16 makes them at HBM rate
+# (25 MB per encoder layer: ~10 us), so C3's encoder (M = 4616: 230 -> 156 us of dgrad per layer) takes this path
+# too (threshold 2048 rows; C3 139.5 -> 140.3 img/s, C2 ~1045 -> 1076).  The copy is keyed on (weights epoch, tensor version, address): the Trainer's fused AdamW writes the
 # parameters through raw pointers, which no autograd version counter sees, so it bumps WEIGHTS_EPOCH.
 # ------------------------------------------------------------------------------------------
 WEIGHTS_EPOCH = 0
-TRANSPOSED_TRAINABLE_MIN_ROWS = int(os.environ.get("ZERO_AMD_DGRAD_T_MIN_ROWS", "8192"))
+TRANSPOSED_TRAINABLE_MIN_ROWS = int(os.environ.get("ZERO_AMD_DGRAD_T_MIN_ROWS", "2048"))
 
 
 def bump_weights_epoch():
@@ -164,7 +172,7 @@ def _step_t(w: torch.Tensor, owner: torch.Tensor) -> torch.Tensor:
     hit = cache.get(key)
     if hit is not None and hit[0] == stamp:
         return hit[1]
-    wt = w.detach().t().contiguous()
+    wt = _transposed(w.detach())
     cache[key] = (stamp, wt)
     return wt
 

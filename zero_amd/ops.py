@@ -414,6 +414,16 @@ def embed_finish(patch, cls, pos, B: int, T: int, D: int):
     return out
 
 
+def transpose(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[C, R] = w[R, C]^T (bf16, rows of w may be strided; R and C multiples of 8)."""
+    _chk2d(w, "w")
+    R, C = w.shape
+    if out is None:
+        out = torch.empty((C, R), dtype=BF16, device=w.device)
+    check(lib.zk_transpose_bf16(_p(w), _p(out), R, C, w.stride(0), out.stride(0), _stream()), "zk_transpose_bf16")
+    return out
+
+
 def gather_rows(table0, table1, codes, D: int, out=None, accumulate: bool = False):
     """out[r] = table0[code] (code>=0) | 0 (code==-1) | table1[-2-code] (code<=-2)."""
     if codes.dtype != torch.int32 or not codes.is_contiguous():
