@@ -870,8 +870,10 @@ __global__ __launch_bounds__(512) void gemm_pring_kernel(GemmArgs g) {
     while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
   // whole-matrix descriptors; the tile origin goes into the (scalar) offset (host: M*lda, N*ldb < 2^30)
-  __amdgpu_buffer_rsrc_t rA = make_rsrc(g.A, 0x7FFFFFF0u);
-  __amdgpu_buffer_rsrc_t rB = make_rsrc(g.B, 0x7FFFFFF0u);
+  // LEAN addresses rows without a bounds test: the descriptors end at the last row, so rows past M / N (ragged
+  // edge tiles) are out of range for the hardware and arrive as zeros (host: M * lda * 2 < 2^31, K % 64 == 0)
+  __amdgpu_buffer_rsrc_t rA = make_rsrc(g.A, LEAN ? (unsigned)g.M * (unsigned)g.lda * 2u : 0x7FFFFFF0u);
+  __amdgpu_buffer_rsrc_t rB = make_rsrc(g.B, LEAN ? (unsigned)g.N * (unsigned)g.ldb * 2u : 0x7FFFFFF0u);
   const unsigned voff_a = (unsigned)((tid >> 3) * g.lda + (((tid & 7) ^ ((tid >> 3) & 7)) * 8)) * 2u;
   const unsigned voff_b = (unsigned)((tid >> 3) * g.ldb + (((tid & 7) ^ ((tid >> 3) & 7)) * 8)) * 2u;
 
@@ -1268,7 +1270,8 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
         const int bm = tile == 4 ? 384 : (tile == 5 ? 192 : 256), bn = tile == 4 ? 192 : 256;
         gr.tiles_m = (g.M + bm - 1) / bm; gr.tiles_n = (g.N + bn - 1) / bn;
         const dim3 rg(gr.tiles_m * gr.tiles_n);
-        const bool lean = g.M % bm == 0 && g.N % bn == 0 && g.K % BK == 0 && P.lean;
+        const bool lean = g.M % bm == 0 && g.N % bn == 0 && g.K % BK == 0 && P.lean;   // one-workgroup-per-tile ring
+        const bool lean_p = g.K % BK == 0 && P.lean;   // persistent ring: ragged M / N fall out of the descriptors
         // persistent ring: needs >= 4 K-tiles per tile and whole-matrix 32-bit byte offsets
         const int pclass = P.ring_mode == 3 ? 3
                            : epilogue == ZK_EPI_NONE ? 0
@@ -1280,7 +1283,7 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
           const int ncu = num_cus();
           const int ntl = gr.tiles_m * gr.tiles_n;
           const dim3 pg(ntl < ncu ? ntl : ncu);
-          g_last_plan = 3000 + tile * 100 + (lean ? 10 : 0) + pclass;
+          g_last_plan = 3000 + tile * 100 + (lean_p ? 10 : 0) + pclass;
           // an XCD holds 32 consecutive tiles of the order = band x (32 / band): its L2 then streams
           // band * BM rows of A and (32 / band) * BN rows of B per K-tile; 384x192 tiles want 4 x 8
           gr.band = P.band > 0 ? P.band : (tile == 4 ? 4 : 8);
@@ -1294,9 +1297,9 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
 #define ZK_PRING(EPI_) \
   do { \
     if (tile == 5) hipLaunchKernelGGL((gemm_pring_kernel<192, 256, 2, 4, 64, 14, true, EPI_>), pg, dim3(512), 0, stream, gr); \
-    else if (tile == 4 && lean) hipLaunchKernelGGL((gemm_pring_kernel<384, 192, 4, 2, 192, 6, true, EPI_>), pg, dim3(512), 0, stream, gr); \
+    else if (tile == 4 && lean_p) hipLaunchKernelGGL((gemm_pring_kernel<384, 192, 4, 2, 192, 6, true, EPI_>), pg, dim3(512), 0, stream, gr); \
     else if (tile == 4) hipLaunchKernelGGL((gemm_pring_kernel<384, 192, 4, 2, 192, 6, false, EPI_>), pg, dim3(512), 0, stream, gr); \
-    else if (lean) hipLaunchKernelGGL((gemm_pring_kernel<256, 256, 2, 4, 128, 9, true, EPI_>), pg, dim3(512), 0, stream, gr); \
+    else if (lean_p) hipLaunchKernelGGL((gemm_pring_kernel<256, 256, 2, 4, 128, 9, true, EPI_>), pg, dim3(512), 0, stream, gr); \
     else hipLaunchKernelGGL((gemm_pring_kernel<256, 256, 2, 4, 128, 9, false, EPI_>), pg, dim3(512), 0, stream, gr); \
   } while (0)
           if (pclass == 0) ZK_PRING(0);
