@@ -135,6 +135,17 @@ int zk_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
                 int64_t S, int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk,
                 int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale,
                 int causal, hipStream_t stream);
+/* zk_attn_bwd with the rotary backward folded into its store epilogues: dq and dk leave as the
+ * gradients of the UN-rotated q / k, bit for bit what zk_rope(..., inverse=1) over the dq / dk
+ * column blocks would leave after zk_attn_bwd (tf:llama:140-160 apply_rotary_pos_emb's backward,
+ * called from tf:llama:248-262).  cos_t / sin_t are the [S][head_dim/2] fp32 tables of zk_rope;
+ * both NULL = zk_attn_bwd. */
+int zk_attn_bwd_rope(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                     const float* lse, float* delta, void* dq, void* dk, void* dv, int64_t B,
+                     int64_t S, int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq,
+                     int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk,
+                     int64_t lddv, float scale, int causal, const float* cos_t,
+                     const float* sin_t, hipStream_t stream);
 
 /* Single-query attention over a KV cache: one new token per sequence against `lens[b]` cached keys
  * (the current token's k/v already appended), as tf generate(use_cache=True) does for the reference's

@@ -392,6 +392,38 @@ def test_attention_online_softmax_rescale_branch():
     assert (lse[0, 0] - rlse[0, 0]).abs().max().item() < 5e-3
 
 
+@pytest.mark.parametrize("B,S,Hq,Hkv,hd,causal", [
+    (2, 200, 6, 2, 128, True),        # ragged S, GQA rep 3
+    (1, 768, 24, 8, 128, True),       # Llama-3.2-3B geometry at S = 768
+    (2, 130, 4, 2, 64, False),
+    (1, 1, 4, 2, 128, False),
+])
+def test_attention_bwd_rotary_epilogue_is_rope_inverse(B, S, Hq, Hkv, hd, causal):
+    """zk_attn_bwd_rope leaves dq / dk exactly as zk_attn_bwd followed by zk_rope(inverse) does (bit for bit), dv
+    as zk_attn_bwd does."""
+    W = (Hq + 2 * Hkv) * hd
+    qkv = rnd(B * S, W, seed=23)
+    q2, k2, v2 = qkv[:, :Hq * hd], qkv[:, Hq * hd:(Hq + Hkv) * hd], qkv[:, (Hq + Hkv) * hd:]
+    scale = hd ** -0.5
+    o, lse = ops.attn_fwd(q2, k2, v2, B, S, Hq, Hkv, hd, scale, causal)
+    d_o = rnd(B * S, Hq * hd, seed=24)
+    inv = 1.0 / (500000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = torch.outer(torch.arange(S + 3).float(), inv)      # a table longer than S is fine
+    cos_t, sin_t = fr.cos().to(DEV).contiguous(), fr.sin().to(DEV).contiguous()
+
+    def run(fused):
+        d = torch.full((B * S, W), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.attn_bwd(q2, k2, v2, o, d_o, lse, d[:, :Hq * hd], d[:, Hq * hd:(Hq + Hkv) * hd], d[:, (Hq + Hkv) * hd:],
+                     B, S, Hq, Hkv, hd, scale, causal, rope=(cos_t, sin_t) if fused else None)
+        if not fused:
+            ops.rope_(d, cos_t, sin_t, S, Hq + Hkv, hd, inverse=True)
+        return d
+
+    plain, fused = run(False), run(True)
+    assert not torch.isnan(fused.float()).any()
+    assert torch.equal(plain, fused)
+
+
 # ------------------------------------------------------------------ norms
 @pytest.mark.parametrize("rows,D", [(577 * 2, 1024), (37, 256), (100, 3072), (8, 4096), (5, 8192)])
 def test_layernorm_fwd(rows, D):

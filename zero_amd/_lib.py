@@ -31,6 +31,8 @@ SIGNATURES = {
     "zk_gemm_last_plan": [],
     "zk_attn_fwd": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "zk_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
+    "zk_attn_bwd_rope": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I,
+                         _P, _P, _P],
     "zk_attn_decode": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P],
     "zk_attn_decode_fused": [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P],
     "zk_attn_decode_fused_static": [_P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P],

@@ -38,6 +38,7 @@ struct AttnArgs {
   const float* lse_in;
   const float* delta;
   float* delta_out;
+  const float *cos_t, *sin_t;    // backward only: when set, dQ and dK leave with the inverse rotary applied
   int B, S, Hq, Hkv;
   int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
   float scale;
@@ -345,6 +346,25 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(Attn
   }
   // dQ leaves through LDS as whole rows (a lane owns 8 bytes of 16 places in one row of the accumulator layout: 32 rows x 16 bytes per store instruction otherwise): the ring is idle once every wave has
   // passed its last tile; each wave owns a [32][HD] bf16 patch, chunk c of row q at chunk c ^ (q % chunks-per-row)
+  constexpr int RPI = 64 / C::CPR;                 // rows per wave-instruction
+  // rotary tables for the rows this lane stores: requested here, ahead of the barrier and the LDS round trip,
+  // so the pass loop below waits for them once instead of once per pass.  The sines are stored signed for the
+  // INVERSE rotation (rope_chunk): +sin for the lower half's lanes, -sin for the upper half's
+  float rcs[32 / RPI][8], rsn[32 / RPI][8];
+  if (a.cos_t) {
+#pragma unroll
+    for (int ps = 0; ps < 32 / RPI; ++ps) {
+      const int row = min(q0 + ps * RPI + lane / C::CPR, a.S - 1);
+      const size_t t = (size_t)row * (HD / 2) + ((lane % C::CPR) & (C::CPR / 2 - 1)) * 8;
+#pragma unroll
+      for (int j4 = 0; j4 < 2; ++j4) {
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(a.cos_t + t + 4 * j4);
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.sin_t + t + 4 * j4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { rcs[ps][4 * j4 + j] = c4[j]; rsn[ps][4 * j4 + j] = (lane % C::CPR) >= C::CPR / 2 ? -s4[j] : s4[j]; }
+      }
+    }
+  }
   __syncthreads();
   {
     unsigned char* ob = smem + wave * (32 * HD * 2);
@@ -358,13 +378,17 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(Attn
         w[1] = pack2bf(dq[d][4 * r4 + 2] * a.scale, dq[d][4 * r4 + 3] * a.scale);
         *reinterpret_cast<u32x2*>(ob + ql * (HD * 2) + (((d * 4 + r4) ^ (ql & (C::CPR - 1))) << 4) + 8 * h) = w;
       }
-    constexpr int RPI = 64 / C::CPR;                 // rows per wave-instruction
     bf16_t* op = a.dq + ((size_t)b * a.S + q0) * a.lddq + head * HD;
 #pragma unroll
     for (int ps = 0; ps < 32 / RPI; ++ps) {
       const int row = ps * RPI + lane / C::CPR, ch = lane % C::CPR;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(ob + row * (HD * 2) + ((ch ^ (row & (C::CPR - 1))) << 4));
-      if (q0 + row < a.S) *reinterpret_cast<u32x4*>(op + (size_t)row * a.lddq + ch * 8) = v;
+      u32x4 v = *reinterpret_cast<const u32x4*>(ob + row * (HD * 2) + ((ch ^ (row & (C::CPR - 1))) << 4));
+      if (q0 + row >= a.S) continue;
+      if (a.cos_t) {   // the rounded row is rotated exactly as zk_rope(inverse) would rotate it in HBM
+        const u32x4 pv = *reinterpret_cast<const u32x4*>(ob + row * (HD * 2) + (((ch ^ (C::CPR / 2)) ^ (row & (C::CPR - 1))) << 4));
+        v = rope_chunk(v, pv, rcs[ps], rsn[ps]);
+      }
+      *reinterpret_cast<u32x4*>(op + (size_t)row * a.lddq + ch * 8) = v;
     }
   }
 }
@@ -531,6 +555,22 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnArgs a) {
   const float* p1 = reinterpret_cast<const float*>(smem + (4 + w) * (32 * XROW));
   constexpr int LPK = HD / 8;          // lanes per key row
   constexpr int KPP = 64 / LPK;        // keys per pass
+  // rotary tables of the dK rows this lane stores, requested ahead of the exchange (see the dQ kernel)
+  float rcs[16 / KPP][8], rsn[16 / KPP][8];
+  if (a.cos_t) {
+#pragma unroll
+    for (int ps = 0; ps < 16 / KPP; ++ps) {
+      const int key = min(kblk * 128 + w * 32 + 16 * g + ps * KPP + lane / LPK, a.S - 1);
+      const size_t t = (size_t)key * (HD / 2) + ((lane % LPK) & (LPK / 2 - 1)) * 8;
+#pragma unroll
+      for (int j4 = 0; j4 < 2; ++j4) {
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(a.cos_t + t + 4 * j4);
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.sin_t + t + 4 * j4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { rcs[ps][4 * j4 + j] = c4[j]; rsn[ps][4 * j4 + j] = (lane % LPK) >= LPK / 2 ? -s4[j] : s4[j]; }
+      }
+    }
+  }
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
     __syncthreads();                   // ring (or the previous exchange) no longer read
@@ -551,15 +591,22 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnArgs a) {
       const int kr = 16 * g + ps * KPP + lane / LPK, ch = lane % LPK;
       const int key = kblk * 128 + w * 32 + kr;
       if (key >= a.S) continue;
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(p0 + kr * (XROW / 4) + ch * 8);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(p0 + kr * (XROW / 4) + ch * 8 + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p1 + kr * (XROW / 4) + ch * 8);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(p1 + kr * (XROW / 4) + ch * 8 + 4);
-      u32x4 o4;
-      o4[0] = pack2bf((a0[0] + b0[0]) * mul, (a0[1] + b0[1]) * mul);
-      o4[1] = pack2bf((a0[2] + b0[2]) * mul, (a0[3] + b0[3]) * mul);
-      o4[2] = pack2bf((a1[0] + b1[0]) * mul, (a1[1] + b1[1]) * mul);
-      o4[3] = pack2bf((a1[2] + b1[2]) * mul, (a1[3] + b1[3]) * mul);
+      auto sum8 = [&](int c) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(p0 + kr * (XROW / 4) + c * 8);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(p0 + kr * (XROW / 4) + c * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p1 + kr * (XROW / 4) + c * 8);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(p1 + kr * (XROW / 4) + c * 8 + 4);
+        u32x4 r;
+        r[0] = pack2bf((a0[0] + b0[0]) * mul, (a0[1] + b0[1]) * mul);
+        r[1] = pack2bf((a0[2] + b0[2]) * mul, (a0[3] + b0[3]) * mul);
+        r[2] = pack2bf((a1[0] + b1[0]) * mul, (a1[1] + b1[1]) * mul);
+        r[3] = pack2bf((a1[2] + b1[2]) * mul, (a1[3] + b1[3]) * mul);
+        return r;
+      };
+      u32x4 o4 = sum8(ch);
+      if (which == 0 && a.cos_t) {   // dK: the rounded row rotated as zk_rope(inverse) would
+        o4 = rope_chunk(o4, sum8(ch ^ (LPK / 2)), rcs[ps], rsn[ps]);
+      }
       *reinterpret_cast<u32x4*>(outp + ((size_t)b * a.S + key) * ldo_ + kvh * HD + ch * 8) = o4;
     }
   }
@@ -982,7 +1029,18 @@ extern "C" int zk_attn_bwd(const void* q, const void* k, const void* v, const vo
                            int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv,
                            int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal,
                            hipStream_t stream) {
+  return zk_attn_bwd_rope(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, S, Hq, Hkv, head_dim, ldq, ldk, ldv, ldo, lddq,
+                          lddk, lddv, scale, causal, nullptr, nullptr, stream);
+}
+
+extern "C" int zk_attn_bwd_rope(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                const float* lse, float* delta, void* dq, void* dk, void* dv, int64_t B, int64_t S,
+                                int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv,
+                                int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal,
+                                const float* cos_t, const float* sin_t, hipStream_t stream) {
   if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv) return ZK_EINVAL;
+  if ((cos_t == nullptr) != (sin_t == nullptr)) return ZK_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(cos_t) | reinterpret_cast<uintptr_t>(sin_t)) & 15) return ZK_EINVAL;
   if (bad_attn(B, S, Hq, Hkv, head_dim, ldq, ldk, ldv, ldo) || ((lddq | lddk | lddv) & 7)) return ZK_EINVAL;
   // the dK/dV kernel addresses one batch element's rows with 32-bit byte offsets
   if (S * ldq * 2 >= 0x7FFFFFF0LL || S * ldo * 2 >= 0x7FFFFFF0LL || S * ldv * 2 >= 0x7FFFFFF0LL || S * ldk * 2 >= 0x7FFFFFF0LL ||
@@ -992,7 +1050,7 @@ extern "C" int zk_attn_bwd(const void* q, const void* k, const void* v, const vo
   AttnArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
   a.d_o = (const bf16_t*)d_o; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
-  a.lse_in = lse; a.delta = delta; a.delta_out = delta;
+  a.lse_in = lse; a.delta = delta; a.delta_out = delta; a.cos_t = cos_t; a.sin_t = sin_t;
   a.B = (int)B; a.S = (int)S; a.Hq = (int)Hq; a.Hkv = (int)Hkv;
   a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv; a.ldo = (int)ldo;
   a.lddq = (int)lddq; a.lddk = (int)lddk; a.lddv = (int)lddv; a.scale = scale;

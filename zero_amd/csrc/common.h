@@ -42,6 +42,27 @@ __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
 __device__ __forceinline__ float lo_bf(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float hi_bf(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
 
+// one rotary pair (x1 at d, x2 at d + hd/2).  Both products are rounded before the add (no fma
+// contraction), so every kernel that rotates produces the same bits as zk_rope.
+__device__ __forceinline__ void rope_pair(float x1, float x2, float cs, float sn, float& o1, float& o2) {
+#pragma clang fp contract(off)
+  o1 = x1 * cs - x2 * sn;
+  o2 = x2 * cs + x1 * sn;
+}
+// rotate one 16-byte chunk of a row: `own` is this lane's chunk, `other` its partner hd/2 away; cs are the 8
+// cosines of the chunk's d range and ss its SIGNED sines: -sin where own is the x1 half, +sin where it is the
+// x2 half (both flipped for the inverse rotation).  own*cos + other*(+-sin) with both products rounded is
+// rope_pair's o1 / o2 bit for bit (x - y*s == x + y*(-s) in IEEE arithmetic).
+__device__ __forceinline__ u32x4 rope_chunk(const u32x4& own, const u32x4& other, const float* cs, const float* ss) {
+#pragma clang fp contract(off)
+  u32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    r[j] = pack2bf(lo_bf(own[j]) * cs[2 * j] + lo_bf(other[j]) * ss[2 * j],
+                   hi_bf(own[j]) * cs[2 * j + 1] + hi_bf(other[j]) * ss[2 * j + 1]);
+  return r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

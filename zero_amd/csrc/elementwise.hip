@@ -57,10 +57,7 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* x, const float* cos_t
     for (int j = 0; j < 8; ++j) { cs[j] = cp[j]; sn[j] = inverse ? -sp[j] : sp[j]; }
     float o1[8], o2[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      o1[j] = a[j] * cs[j] - b[j] * sn[j];   // x1*cos + (-x2)*sin
-      o2[j] = b[j] * cs[j] + a[j] * sn[j];   // x2*cos + ( x1)*sin
-    }
+    for (int j = 0; j < 8; ++j) rope_pair(a[j], b[j], cs[j], sn[j], o1[j], o2[j]);   // x1*cos - x2*sin, x2*cos + x1*sin
     *reinterpret_cast<u32x4*>(p) = pack8(o1);
     *reinterpret_cast<u32x4*>(p + half) = pack8(o2);
   }

@@ -536,8 +536,8 @@ class DecoderLayerFn(torch.autograd.Function):
         d_qkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
         ops.attn_bwd(q, k, v, ao, d_ao, lse, d_qkv[:, :nh * hd], d_qkv[:, nh * hd:(nh + nkv) * hd],
-                     d_qkv[:, (nh + nkv) * hd:], B, S, nh, nkv, hd, hd ** -0.5, S > 1)
-        ops.rope_(d_qkv, cos_t, sin_t, S, nh + nkv, hd, inverse=True)
+                     d_qkv[:, (nh + nkv) * hd:], B, S, nh, nkv, hd, hd ** -0.5, S > 1,
+                     rope=(cos_t, sin_t))      # the rotary backward rides on the dq / dk stores
         g_qw = _wgrad(d_qkv[:, :nh * hd], h1, qw, nig[2])
         g_kw = _wgrad(d_qkv[:, nh * hd:(nh + nkv) * hd], h1, kw, nig[3])
         g_vw = _wgrad(d_qkv[:, (nh + nkv) * hd:], h1, vw, nig[4])

@@ -211,18 +211,26 @@ def attn_fwd(q, k, v, B: int, S: int, Hq: int, Hkv: int, hd: int, scale: float, 
 
 
 def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B: int, S: int, Hq: int, Hkv: int, hd: int, scale: float,
-             causal: bool):
-    """Writes dq/dk/dv (row-strided views, may be slices of one packed d_qkv buffer)."""
+             causal: bool, rope=None):
+    """Writes dq/dk/dv (row-strided views, may be slices of one packed d_qkv buffer).  rope = (cos, sin)
+    fp32 [S, hd/2] tables: dq / dk then leave with the inverse rotary applied (= rope_(inverse=True) after)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (d_o, "d_o"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
         _chk2d(t, n)
     if o.stride(0) != d_o.stride(0):
         raise ValueError("attn_bwd: o and d_o must share a row stride")
     _chk_flat(lse, "lse", torch.float32)
     delta = torch.empty_like(lse)
-    rc = lib.zk_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, S, Hq,
-                         Hkv, hd, q.stride(0), k.stride(0), v.stride(0), o.stride(0), dq.stride(0), dk.stride(0),
-                         dv.stride(0), float(scale), int(causal), _stream())
-    check(rc, "zk_attn_bwd")
+    cos_t = sin_t = None
+    if rope is not None:
+        cos_t, sin_t = rope
+        for t, n in ((cos_t, "cos"), (sin_t, "sin")):
+            _chk_flat(t, n, torch.float32)
+            if t.dim() != 2 or t.shape[0] < S or t.shape[1] != hd // 2:
+                raise ValueError(f"attn_bwd: {n} table must be [>=S, hd/2]")
+    rc = lib.zk_attn_bwd_rope(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, S,
+                              Hq, Hkv, hd, q.stride(0), k.stride(0), v.stride(0), o.stride(0), dq.stride(0),
+                              dk.stride(0), dv.stride(0), float(scale), int(causal), _p(cos_t), _p(sin_t), _stream())
+    check(rc, "zk_attn_bwd_rope")
 
 
 def attn_decode(q, k_cache, v_cache, lens_i32, max_len: int, Hq: int, Hkv: int, hd: int, scale: float, out=None):
