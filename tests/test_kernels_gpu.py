@@ -185,12 +185,14 @@ def test_gemm_persistent_ring(M, N, K, tile):
         ops.set_gemm_tile(-1)
 
 
-@pytest.mark.parametrize("M,N,K", [(6144, 4096, 512), (1536, 2048, 320), (6144, 14336, 256)])
+@pytest.mark.parametrize("M,N,K", [(6144, 4096, 512), (1536, 2048, 320), (6144, 14336, 256), (4616, 4096, 1024),
+                                   (5000, 4104, 256)])
 def test_gemm_persistent_ring_192x256(M, N, K):
     """The 192x256 tile of the persistent ring (two K-tiles of 7 x 64-row slots: a wave's rows span slots):
-    taken for exact shapes, BIT-equal to the 256x256 ring for every epilogue class, repeatable."""
+    exact and ragged shapes (K a multiple of 64), BIT-equal to the 256x256 ring for every epilogue class, repeatable."""
     a, b = rnd(M, K, seed=57), rnd(N, K, seed=58, scale=0.5)
     bias, res = rnd(N, seed=59), rnd(M, N, seed=60)
+    swiglu = N % 64 == 0
     F = N // 2
     wd_t, gu = rnd(F, K, seed=64, scale=0.2), rnd(M, 2 * F, seed=65)
     try:
@@ -203,8 +205,8 @@ def test_gemm_persistent_ring_192x256(M, N, K):
             aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
             c2 = ops.gemm(a, b, bias=bias, epilogue=ops.EPI_QUICK_GELU, aux_out=aux)
             c3 = ops.gemm(a, b, out=res.clone(), accumulate=True)
-            gu_i, h = ops.gemm_swiglu(a, b)
-            dgu = ops.gemm_swiglu_bwd(a, wd_t, gu)
+            gu_i, h = ops.gemm_swiglu(a, b) if swiglu else (c0, c0)
+            dgu = ops.gemm_swiglu_bwd(a, wd_t, gu) if swiglu else c0
             outs[tile] = (c0, c1, aux, c2, c3, gu_i, h, dgu)
         assert relerr(outs[5][0], a.float() @ b.float().t()) < 6e-3
         for x, y in zip(outs[5], outs[2]):
@@ -213,8 +215,10 @@ def test_gemm_persistent_ring_192x256(M, N, K):
         for _ in range(5):
             assert torch.equal(ops.gemm(a, b), outs[5][0])
         ops.set_gemm_tile(5)
-        ragged = ops.gemm(a[: M - 8], b)                                  # not a multiple of 192: falls back to 256x256
-        assert ops.lib.zk_gemm_last_plan() // 100 == 32 and torch.equal(ragged, outs[2][0][: M - 8])
+        ragged = ops.gemm(a[: M - 8], b)                                  # ragged rows fall out of the DMA descriptors
+        assert ops.lib.zk_gemm_last_plan() // 100 == 35 and torch.equal(ragged, outs[2][0][: M - 8])
+        odd_k = ops.gemm(a[:, : K - 8], b[:, : K - 8])                    # K not a multiple of 64: 256x256 ring
+        assert ops.lib.zk_gemm_last_plan() // 100 == 32
     finally:
         ops.set_gemm_tile(-1)
 

@@ -1137,7 +1137,7 @@ int choose_tile(int64_t M, int64_t N, int64_t K, int transA, int transB, bool ne
   if (P.tile >= 0) {
     if (P.tile == 3 && (transB || need_tn4)) return 0;
     if (P.tile == 4 && (!nt_ring || need_tn4)) return 2;
-    if (P.tile == 5 && !(nt_ring && P.pring && M % 192 == 0 && N % 256 == 0 && K % BK == 0 && K >= 4 * BK)) return 2;
+    if (P.tile == 5 && !(nt_ring && P.pring && (P.lean || (M % 192 == 0 && N % 256 == 0)) && K % BK == 0 && K >= 4 * BK)) return 2;
     return P.tile;
   }
   const int bm[6] = {128, 256, 256, 128, 384, 192}, bn[6] = {128, 128, 256, 96, 192, 256};
@@ -1149,9 +1149,11 @@ int choose_tile(int64_t M, int64_t N, int64_t K, int transA, int transB, bool ne
   // at K = 14336)
   const double kf = K <= 2048 ? 0.0 : (K >= 4096 ? 1.0 : (double)(K - 2048) / 2048.0);
   const double pr = 1.2 + 0.15 * kf;
-  // 192x256 (persistent ring, exact shapes only): 9.1 B/kFLOP of operand traffic against 7.8 — it wins where it
-  // removes a partial round (M = 6144, N = 4096: 512 tiles = two per CU, against 384 tiles of 256x256 = 1.5)
-  const bool t5 = nt_ring && P.pring && M % 192 == 0 && N % 256 == 0 && K % BK == 0 && K >= 4 * BK;
+  // 192x256 (persistent ring): 9.1 B/kFLOP of operand traffic against 7.8 — it wins where it removes a partial
+  // round (M = 6144, N = 4096: 512 tiles = two per CU, against 384 tiles of 256x256 = 1.5; the encoder's fc1 at
+  // M = 4616: 400 tiles, 16 of them 8 rows tall, 42 us against 52 us on 128x128).  Ragged M / N ride on the lean
+  // descriptors.
+  const bool t5 = nt_ring && P.pring && (P.lean || (M % 192 == 0 && N % 256 == 0)) && K % BK == 0 && K >= 4 * BK;
   const double eff[6] = {1.0, 0.9, nt_ring ? pr : 1.02, 0.93, pr, pr * 0.94};
   int best = 0;
   double best_cost = 1e300;
