@@ -42,6 +42,8 @@ SHAPES = [  # (name, M, N, K, trans_a, trans_b)
     ("c2 fc1     NT", 36928, 4096, 1024, False, False),
     ("c2 fc2     NT", 36928, 1024, 4096, False, False),
     ("c2 qkv     NT", 36928, 3072, 1024, False, False),
+    ("c2 o       NT", 36928, 1024, 1024, False, False),
+    ("c2 d_qkv   NT", 36928, 1024, 3072, False, False),
 ]
 
 

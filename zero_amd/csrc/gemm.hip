@@ -1143,12 +1143,12 @@ int choose_tile(int64_t M, int64_t N, int64_t K, int transA, int transB, bool ne
   const int bm[6] = {128, 256, 256, 128, 384, 192}, bn[6] = {128, 128, 256, 96, 192, 256};
   const double slots[6] = {512.0, 256.0, 256.0, 512.0, 256.0, 256.0};   // two 4-wave blocks or one 8-wave block per CU
   // measured on MI355X (tools/bench_gemm.py); the slot-ring kernels exist for NT products only.  The persistent
-  // ring's advantage grows with K (its ring fill and store burst amortise): 1.2 at K <= 2048 (encoder fc1 at
-  // K = 1024 stays on 128x128: 51 us vs 61 us), 1.35 from K = 4096 (the N = 4096 products of the 8B surrogate:
-  // 384 tiles of 256x256 in two rounds beat 1536 tiles of 128x128 in three, 178 vs 190 us at K = 4096, 630 vs 727 us
-  // at K = 14336)
+  // ring's advantage grows with K (its ring fill and store burst amortise): 1.3 at K <= 2048 (M = 36928, N = 1024,
+  // K = 1024: 580 tiles of 256x256 in three rounds 78 us, 2312 tiles of 128x128 in five 90 us; encoder fc1 at
+  // M = 4616: 51 us against 52 us), 1.35 from K = 4096 (the N = 4096 products of the 8B surrogate: 384 tiles of
+  // 256x256 in two rounds beat 1536 tiles of 128x128 in three, 178 vs 190 us at K = 4096, 630 vs 727 us at K = 14336)
   const double kf = K <= 2048 ? 0.0 : (K >= 4096 ? 1.0 : (double)(K - 2048) / 2048.0);
-  const double pr = 1.2 + 0.15 * kf;
+  const double pr = 1.3 + 0.05 * kf;
   // 192x256 (persistent ring): 9.1 B/kFLOP of operand traffic against 7.8 — it wins where it removes a partial
   // round (M = 6144, N = 4096: 512 tiles = two per CU, against 384 tiles of 256x256 = 1.5; the encoder's fc1 at
   // M = 4616: 400 tiles, 16 of them 8 rows tall, 42 us against 52 us on 128x128).  Ragged M / N ride on the lean
