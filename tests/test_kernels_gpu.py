@@ -426,6 +426,17 @@ def test_attention_bwd_rotary_epilogue_is_rope_inverse(B, S, Hq, Hkv, hd, causal
     plain, fused = run(False), run(True)
     assert not torch.isnan(fused.float()).any()
     assert torch.equal(plain, fused)
+    # a table shorter than S, or one table without the other, is refused before anything is launched
+    d = torch.empty((B * S, W), dtype=torch.bfloat16, device=DEV)
+    args = (q2, k2, v2, o, d_o, lse, d[:, :Hq * hd], d[:, Hq * hd:(Hq + Hkv) * hd], d[:, (Hq + Hkv) * hd:], B, S, Hq, Hkv,
+            hd, scale, causal)
+    if S > 1:
+        with pytest.raises(ValueError):
+            ops.attn_bwd(*args, rope=(cos_t[: S - 1], sin_t[: S - 1]))
+    rc = ops.lib.zk_attn_bwd_rope(q2.data_ptr(), k2.data_ptr(), v2.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
+                                  torch.empty_like(lse).data_ptr(), d.data_ptr(), d.data_ptr(), d.data_ptr(), B, S, Hq, Hkv,
+                                  hd, W, W, W, Hq * hd, W, W, W, scale, int(causal), cos_t.data_ptr(), None, None)
+    assert rc == -22      # ZK_EINVAL (-EINVAL)
 
 
 # ------------------------------------------------------------------ norms
