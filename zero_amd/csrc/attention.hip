@@ -97,13 +97,14 @@ __device__ __forceinline__ bf16x8 tr_frag_sw(const unsigned char* lds, int k0, i
 // two blocks per CU.  One barrier per tile: "tile t landed everywhere and tile t-1 is consumed",
 // after which the stage of tile t-1 is refilled with tile t+NST-1.
 // =========================================================================================
-template <int HD>
+template <int HD, int NST_>
 struct KvRing {
   static constexpr int KV = 64;
   static constexpr int RB = HD * 2;
   static constexpr int TILE = KV * RB;
   static constexpr int STAGE = 2 * TILE;
-  static constexpr int NST = HD == 128 ? 2 : 3;            // 64 KiB (hd 128) / 48 KiB (hd 64: three blocks per CU)
+  static constexpr int NST = NST_;   // hd 128: 2 stages (64 KiB, two blocks per CU); hd 64: 2 in the forward (32 KiB, four
+                                     // blocks per CU at 128 VGPRs: 165 -> 158 us at B = 64), 3 in dQ (48 KiB, three blocks)
   static constexpr int NQ = KV * (HD / 8) / 256;           // 16-byte DMA instructions per thread per operand tile
   static constexpr int PER = 2 * NQ;
 
@@ -132,9 +133,9 @@ struct KvRing {
 };
 
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_fwd_kernel(AttnArgs a) {
   using C = Cfg<HD>;
-  using R = KvRing<HD>;
+  using R = KvRing<HD, 2>;
   constexpr int KV = R::KV;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[R::NST * R::STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_fwd_kernel(AttnArg
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(AttnArgs a) {
   using C = Cfg<HD>;
-  using R = KvRing<HD>;
+  using R = KvRing<HD, HD == 128 ? 2 : 3>;
   constexpr int KV = R::KV;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[R::NST * R::STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
