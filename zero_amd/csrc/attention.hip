@@ -351,21 +351,23 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(Attn
   // rotary tables for the rows this lane stores: requested here, ahead of the barrier and the LDS round trip,
   // so the pass loop below waits for them once instead of once per pass.  The sines are stored signed for the
   // INVERSE rotation (rope_chunk): +sin for the lower half's lanes, -sin for the upper half's
-  float rcs[32 / RPI][8], rsn[32 / RPI][8];
-  if (a.cos_t) {
+  // (hd 128: 8 passes x 16 values would not fit beside the live accumulators — the compiler spilled — so the
+  // second half is requested once the accumulators have gone to LDS)
+  constexpr int NPS = 32 / RPI, NPRE = NPS > 4 ? 4 : NPS;
+  float rcs[NPS][8], rsn[NPS][8];
+  auto load_tab = [&](auto ps_c) {
+    constexpr int ps = decltype(ps_c)::value;
+    const int row = min(q0 + ps * RPI + lane / C::CPR, a.S - 1);
+    const size_t t = (size_t)row * (HD / 2) + ((lane % C::CPR) & (C::CPR / 2 - 1)) * 8;
 #pragma unroll
-    for (int ps = 0; ps < 32 / RPI; ++ps) {
-      const int row = min(q0 + ps * RPI + lane / C::CPR, a.S - 1);
-      const size_t t = (size_t)row * (HD / 2) + ((lane % C::CPR) & (C::CPR / 2 - 1)) * 8;
+    for (int j4 = 0; j4 < 2; ++j4) {
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(a.cos_t + t + 4 * j4);
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.sin_t + t + 4 * j4);
 #pragma unroll
-      for (int j4 = 0; j4 < 2; ++j4) {
-        const f32x4 c4 = *reinterpret_cast<const f32x4*>(a.cos_t + t + 4 * j4);
-        const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.sin_t + t + 4 * j4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { rcs[ps][4 * j4 + j] = c4[j]; rsn[ps][4 * j4 + j] = (lane % C::CPR) >= C::CPR / 2 ? -s4[j] : s4[j]; }
-      }
+      for (int j = 0; j < 4; ++j) { rcs[ps][4 * j4 + j] = c4[j]; rsn[ps][4 * j4 + j] = (lane % C::CPR) >= C::CPR / 2 ? -s4[j] : s4[j]; }
     }
-  }
+  };
+  if (a.cos_t) static_for<NPRE>([&](auto ps_c) { load_tab(ps_c); });
   __syncthreads();
   {
     unsigned char* ob = smem + wave * (32 * HD * 2);
@@ -379,18 +381,20 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(Attn
         w[1] = pack2bf(dq[d][4 * r4 + 2] * a.scale, dq[d][4 * r4 + 3] * a.scale);
         *reinterpret_cast<u32x2*>(ob + ql * (HD * 2) + (((d * 4 + r4) ^ (ql & (C::CPR - 1))) << 4) + 8 * h) = w;
       }
+    if (a.cos_t) static_for<NPS - NPRE>([&](auto k_c) { load_tab(std::integral_constant<int, NPRE + decltype(k_c)::value>{}); });
     bf16_t* op = a.dq + ((size_t)b * a.S + q0) * a.lddq + head * HD;
-#pragma unroll
-    for (int ps = 0; ps < 32 / RPI; ++ps) {
+    static_for<NPS>([&](auto ps_c) {
+      constexpr int ps = decltype(ps_c)::value;
       const int row = ps * RPI + lane / C::CPR, ch = lane % C::CPR;
       u32x4 v = *reinterpret_cast<const u32x4*>(ob + row * (HD * 2) + ((ch ^ (row & (C::CPR - 1))) << 4));
-      if (q0 + row >= a.S) continue;
-      if (a.cos_t) {   // the rounded row is rotated exactly as zk_rope(inverse) would rotate it in HBM
-        const u32x4 pv = *reinterpret_cast<const u32x4*>(ob + row * (HD * 2) + (((ch ^ (C::CPR / 2)) ^ (row & (C::CPR - 1))) << 4));
-        v = rope_chunk(v, pv, rcs[ps], rsn[ps]);
+      if (q0 + row < a.S) {
+        if (a.cos_t) {   // the rounded row is rotated exactly as zk_rope(inverse) would rotate it in HBM
+          const u32x4 pv = *reinterpret_cast<const u32x4*>(ob + row * (HD * 2) + (((ch ^ (C::CPR / 2)) ^ (row & (C::CPR - 1))) << 4));
+          v = rope_chunk(v, pv, rcs[ps], rsn[ps]);
+        }
+        *reinterpret_cast<u32x4*>(op + (size_t)row * a.lddq + ch * 8) = v;
       }
-      *reinterpret_cast<u32x4*>(op + (size_t)row * a.lddq + ch * 8) = v;
-    }
+    });
   }
 }
 

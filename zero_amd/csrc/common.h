@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+#include <utility>
 
 typedef uint16_t bf16_t;  // raw bf16 bits in HBM
 
@@ -24,6 +26,16 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
     hipError_t e__ = hipGetLastError();                     \
     if (e__ != hipSuccess) return ZK_ELAUNCH;               \
   } while (0)
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 __device__ __forceinline__ float bf2f(bf16_t v) {
   return __uint_as_float(((unsigned int)v) << 16);

@@ -669,15 +669,6 @@ __global__ __launch_bounds__(512) void gemm_ringx_kernel(GemmArgs g) {
 //   256x256: RS 128, 9 slots of 16 KiB (2.25 K-tiles) + 16 KiB patch = 160 KiB
 //   384x192: RS 192, 6 slots of 24 KiB (2 K-tiles)    + 16 KiB patch = 160 KiB, waves 4(M) x 2(N)
 // ------------------------------------------------------------------------------------------
-template <class F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
 __device__ __forceinline__ int patch_swz(int r) { return ((r >> 1) & 3) | ((r & 1) << 2); }
 
 // Epilogue of one wave's (TM*16) x (TN*16) sub-tile through its private 16 x 32 fp32 LDS patch.
