@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ZK_ABI_VERSION 3
+#define ZK_ABI_VERSION 4
 int zk_abi_version(void);
 
 /* ---- GEMM -------------------------------------------------------------------------

@@ -67,7 +67,7 @@ for _name, _args in SIGNATURES.items():
     _fn.argtypes = _args
     _fn.restype = c_int
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 if lib.zk_abi_version() != ABI_VERSION:
     raise ImportError("libzero_hip.so ABI version mismatch; rebuild with `make -C zero_amd/csrc`")
 
