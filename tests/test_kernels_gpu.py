@@ -361,6 +361,8 @@ def ref_attention(q, k, v, causal, scale):
     (1, 768, 24, 8, 128, True),       # Llama-3.2-3B geometry at S = 768
     (1, 130, 4, 1, 128, False),
     (1, 100, 2, 2, 64, True),
+    (48, 130, 16, 16, 64, False),     # 1536 key blocks: the 4-wave dK/dV block (two query halves per wave)
+    (64, 200, 12, 4, 64, True),       # the same, causal, GQA rep 3
 ])
 def test_attention_fwd_bwd(B, S, Hq, Hkv, hd, causal):
     W = (Hq + 2 * Hkv) * hd

@@ -410,22 +410,27 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(Attn
 // both read kinds (b128 row fragments, b64 transposed fragments) are removed by XOR-swizzling
 // the 16-byte chunk index on the DMA's SOURCE address and again on the reads.
 // =========================================================================================
-template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnArgs a) {
+// GW = query halves spread ACROSS waves: 2 = the 8-wave block above; 1 = a 4-wave block whose waves walk both 32-row
+// halves of a tile themselves (hd 64: two independent S / dP / softmax chains per wave and tile give the in-order
+// wave something to issue while the other chain waits, two blocks per CU, and the halves already meet in the
+// accumulators, so the exchange only reshapes).
+template <int HD, bool CAUSAL, int GW>
+__global__ __launch_bounds__(256 * GW, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
   using C = Cfg<HD>;
-  constexpr int QT = 64, NST = 3;
+  constexpr int QT = 64, NST = 3, NT = 256 * GW;
   constexpr int RB = HD * 2;                       // LDS row bytes (unpadded)
   constexpr int TILE = QT * RB;
   constexpr int STAGE = 2 * TILE + 2048;           // Q tile, dO tile, 8 x 256 B of per-wave dword DMA (lse, delta, 6 unused)
   constexpr int VBYTES = 128 * RB;                 // the block's V rows stay in LDS (their fragments would not fit in VGPRs beside K's)
-  constexpr int NQ = QT * C::CPR / 512;            // 16-byte DMA instructions per thread per tile (Q; same for dO)
+  constexpr int NQ = QT * C::CPR / NT;             // 16-byte DMA instructions per thread per tile (Q; same for dO)
+  static_assert(NQ * NT == QT * C::CPR && (128 * C::CPR) % NT == 0, "tile pieces per thread");
   constexpr int PER = 2 * NQ + 1;
   constexpr int XROW = HD * 4 + 16;                // exchange patch row (fp32 + pad)
-  static_assert(NST * STAGE + VBYTES >= 8 * 32 * XROW, "the dK/dV exchange reuses the ring");
+  static_assert(NST * STAGE + VBYTES >= 4 * GW * 32 * XROW, "the dK/dV exchange reuses the ring");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE + VBYTES];
   unsigned char* const vl = smem + NST * STAGE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int g = wave >> 2, w = wave & 3;
+  const int g0 = GW == 2 ? wave >> 2 : 0, w = wave & 3;
   const int nbh = a.Hkv * a.B;  // 1-D grid, heaviest (causal: earliest) key blocks first
   const int kblk = CAUSAL ? (int)(blockIdx.x / nbh) : (int)(gridDim.x / nbh) - 1 - (int)(blockIdx.x / nbh);
   const int kvh = (blockIdx.x % nbh) % a.Hkv, b = (blockIdx.x % nbh) / a.Hkv;
@@ -463,10 +468,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnArgs a) {
     const int qb = (qt0 + it % nqt) * QT;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-      const int sidx = tid + 512 * i;
+      const int sidx = tid + NT * i;
       const int row = sidx / C::CPR, ch = (sidx % C::CPR) ^ swz_key<HD>(row);
       const bool ok = qb + row < a.S;
-      unsigned char* dst = st + ((tid & ~63) + 512 * i) * 16;   // wave-uniform; the hardware adds lane * 16
+      unsigned char* dst = st + ((tid & ~63) + NT * i) * 16;   // wave-uniform; the hardware adds lane * 16
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)dst, 16,
                                                ok ? (unsigned)(((qb + row) * a.ldq + hq * HD + ch * 8) * 2) : 0xFFFFFFF0u, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (__attribute__((address_space(3))) void*)(dst + TILE), 16,
@@ -487,11 +492,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnArgs a) {
     // V rows of the block, same swizzled image (issued first: landed before tile 0 is waited for)
     __amdgpu_buffer_rsrc_t rv = make_rsrc(a.v + (size_t)b * a.S * a.ldv, 0x7FFFFFF0u);
 #pragma unroll
-    for (int i = 0; i < 128 * C::CPR / 512; ++i) {
-      const int sidx = tid + 512 * i;
+    for (int i = 0; i < 128 * C::CPR / NT; ++i) {
+      const int sidx = tid + NT * i;
       const int row = sidx / C::CPR, ch = (sidx % C::CPR) ^ swz_key<HD>(row);
       const bool ok = kblk * 128 + row < a.S;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(vl + ((tid & ~63) + 512 * i) * 16), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(vl + ((tid & ~63) + NT * i) * 16), 16,
                                                ok ? (unsigned)(((kblk * 128 + row) * a.ldv + kvh * HD + ch * 8) * 2) : 0xFFFFFFF0u, 0, 0, 0);
     }
   }
@@ -508,9 +513,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnArgs a) {
     const unsigned char* dol = st + TILE;
     const float* lsl = reinterpret_cast<const float*>(st + 2 * TILE);
     const float* dll = reinterpret_cast<const float*>(st + 2 * TILE + 256);
+#pragma unroll
+    for (int gg = 0; gg < 3 - GW; ++gg) {
+    const int g = g0 + gg;
     const int qb = (qt0 + it % nqt) * QT + 32 * g;   // this wave's 32 rows
-    // causal: this wave's keys are all after its last query -> nothing to do; same for rows past S
-    const bool skip = (CAUSAL && (k0w > qb + 31)) || qb >= a.S;
+    // causal: this wave's keys are all after its last query -> nothing to do; same for rows past S.  (A wave that
+    // walks both halves keeps them in one basic block when nothing is causal: rows past S arrive as zeros, their
+    // p is forced to 0 below, and the compiler may interleave the two chains.)
+    const bool skip = (CAUSAL && (k0w > qb + 31)) || ((GW == 2 || CAUSAL) && qb >= a.S);
     if (!skip) {
       // The ~40 swizzled fragment addresses are loop-invariant; hoisted they cost 40 VGPRs the
       // kernel does not have (spills, whose scratch loads would also break the counted vmcnt).
@@ -550,6 +560,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnArgs a) {
         }
       }
     }
+    }
   }
 
   // ---- the two query halves meet: every wave parks one accumulator set in its fp32 patch
@@ -557,15 +568,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnArgs a) {
   // and writes whole rows (8 consecutive d per lane).  dK first, then dV through the same patches.
   float* patch = reinterpret_cast<float*>(smem + wave * (32 * XROW));
   const float* p0 = reinterpret_cast<const float*>(smem + w * (32 * XROW));
-  const float* p1 = reinterpret_cast<const float*>(smem + (4 + w) * (32 * XROW));
+  const float* p1 = reinterpret_cast<const float*>(smem + ((GW == 2 ? 4 : 0) + w) * (32 * XROW));   // (GW 1: unused)
   constexpr int LPK = HD / 8;          // lanes per key row
   constexpr int KPP = 64 / LPK;        // keys per pass
+  constexpr int RPW = 32 / GW;         // key rows a wave finishes
   // rotary tables of the dK rows this lane stores, requested ahead of the exchange (see the dQ kernel)
-  float rcs[16 / KPP][8], rsn[16 / KPP][8];
+  float rcs[RPW / KPP][8], rsn[RPW / KPP][8];
   if (a.cos_t) {
 #pragma unroll
-    for (int ps = 0; ps < 16 / KPP; ++ps) {
-      const int key = min(kblk * 128 + w * 32 + 16 * g + ps * KPP + lane / LPK, a.S - 1);
+    for (int ps = 0; ps < RPW / KPP; ++ps) {
+      const int key = min(kblk * 128 + w * 32 + RPW * g0 + ps * KPP + lane / LPK, a.S - 1);
       const size_t t = (size_t)key * (HD / 2) + ((lane % LPK) & (LPK / 2 - 1)) * 8;
 #pragma unroll
       for (int j4 = 0; j4 < 2; ++j4) {
@@ -592,15 +604,18 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnArgs a) {
     bf16_t* outp = which == 0 ? a.dk : a.dv;
     const int ldo_ = which == 0 ? a.lddk : a.lddv;
 #pragma unroll
-    for (int ps = 0; ps < 16 / KPP; ++ps) {
-      const int kr = 16 * g + ps * KPP + lane / LPK, ch = lane % LPK;
+    for (int ps = 0; ps < RPW / KPP; ++ps) {
+      const int kr = RPW * g0 + ps * KPP + lane / LPK, ch = lane % LPK;
       const int key = kblk * 128 + w * 32 + kr;
       if (key >= a.S) continue;
       auto sum8 = [&](int c) {
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(p0 + kr * (XROW / 4) + c * 8);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(p0 + kr * (XROW / 4) + c * 8 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p1 + kr * (XROW / 4) + c * 8);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(p1 + kr * (XROW / 4) + c * 8 + 4);
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (GW == 2) {
+          b0 = *reinterpret_cast<const f32x4*>(p1 + kr * (XROW / 4) + c * 8);
+          b1 = *reinterpret_cast<const f32x4*>(p1 + kr * (XROW / 4) + c * 8 + 4);
+        }
         u32x4 r;
         r[0] = pack2bf((a0[0] + b0[0]) * mul, (a0[1] + b0[1]) * mul);
         r[1] = pack2bf((a0[2] + b0[2]) * mul, (a0[3] + b0[3]) * mul);
@@ -1063,20 +1078,27 @@ extern "C" int zk_attn_bwd_rope(const void* q, const void* k, const void* v, con
   dim3 gq((unsigned)(((S + 127) / 128) * Hq * B));
   dim3 gk((unsigned)(((S + 127) / 128) * Hkv * B)), bk(512);
   if (head_dim == 64) {
+    // dK/dV block shape: 8 waves (one block per CU, 256 slots) or 4 waves walking both query halves (two blocks per
+    // CU, 512 slots, each twice as long but ~15 % cheaper per unit of work: 721 -> 653 us at B = 64).  Rounds x
+    // block time decides: small grids (B = 8: 640 blocks = 3 short rounds against 2 long ones) keep the 8-wave block.
+    const double r8 = (double)((gk.x + 255) / 256), r4 = (double)((gk.x + 511) / 512) * 2.0 * 0.85;
+    const bool four = r4 < r8;
     if (causal) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, block, 0, stream, a);
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, true>), gk, bk, 0, stream, a);
+      if (four) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, true, 1>), gk, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, true, 2>), gk, bk, 0, stream, a);
     } else {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false>), gq, block, 0, stream, a);
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, false>), gk, bk, 0, stream, a);
+      if (four) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, false, 1>), gk, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, false, 2>), gk, bk, 0, stream, a);
     }
   } else {
     if (causal) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), gq, block, 0, stream, a);
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, true>), gk, bk, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, true, 2>), gk, bk, 0, stream, a);
     } else {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<128, false>), gq, block, 0, stream, a);
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false>), gk, bk, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false, 2>), gk, bk, 0, stream, a);
     }
   }
   ZK_CHECK_LAUNCH();
