@@ -179,7 +179,9 @@ int zk_attn_decode_fused(const void* qkv, const float* cos_row, const float* sin
  * the array's address up (hipGetSymbolAddress; make that first call outside a capture).
  * Limit: B * Hq * (pos / 64 + 1) * (head_dim + 2) <= ZK_ATTN_DECODE_STATIC_FLOATS, otherwise -7 (E2BIG) and nothing
  * is launched (e.g. 8 q heads x hd 128, B = 1: 129,000 cached keys; 32 heads, B = 4: 8,064).
- * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams) race. */
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams) race.
+ * The current device must be the one `stream` belongs to (each GPU has its own copy of the array at its own
+ * address): -22 otherwise.  Argument errors are reported (-22) before the size limit (-7). */
 #define ZK_ATTN_DECODE_STATIC_FLOATS (2 * 1024 * 1024)
 int zk_attn_decode_fused_static(const void* qkv, const float* cos_row, const float* sin_row, void* k_cache,
                                 void* v_cache, void* out, int64_t B, int64_t Hq, int64_t Hkv, int64_t head_dim,

@@ -137,3 +137,39 @@ def test_trainer_state_dict_is_torch_adamw_layout(tmp_path):
         assert tr.global_step == 77
     finally:
         tr.reducer.close()
+
+
+def test_saved_lr_matches_cosine_annealing_with_min_lr():
+    """``cfg.min_lr > 0``: the rate the Trainer applies, the ``lr`` it saves in ``param_groups`` and the scheduler
+    view's ``_last_lr`` must all equal torch's CosineAnnealingLR(eta_min=min_lr) after N steps — torch's scheduler is
+    recursive on ``group['lr']``, so a checkpoint with ``lr = base * factor`` would resume from a wrong rate."""
+    from zero_amd.train import Trainer
+    cfg, model, _ = _model()
+    cfg.min_lr = 1e-6
+    groups = func_optim_filter(cfg, model)
+    T, N = 40, 7
+    tr = Trainer(cfg, model, lambda self, c: None, groups, total_steps=T)
+    try:
+        ref_groups = func_optim_filter(cfg, model)
+        opt = torch.optim.AdamW(ref_groups, betas=(cfg.adamw_beta1, cfg.adamw_beta2), eps=1e-8)
+        sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=T, eta_min=cfg.min_lr)
+        for _ in range(N):
+            opt.step(); sch.step()
+        tr.global_step = N
+        want = sch.get_last_lr()
+        sd, ssd = tr.state_dict(), tr.scheduler.state_dict()
+        for i, g in enumerate(tr._groups):
+            assert abs(tr.current_lr(g["lr"], N) - want[i]) <= 1e-9 * want[i]
+            assert abs(sd["param_groups"][i]["lr"] - want[i]) <= 1e-9 * want[i]
+            assert abs(ssd["_last_lr"][i] - want[i]) <= 1e-9 * want[i]
+        assert ssd["eta_min"] == cfg.min_lr
+        # loaded into fresh torch objects, the next scheduler step continues exactly as the uninterrupted run does
+        opt2 = torch.optim.AdamW(func_optim_filter(cfg, model), betas=(cfg.adamw_beta1, cfg.adamw_beta2), eps=1e-8)
+        sch2 = torch.optim.lr_scheduler.CosineAnnealingLR(opt2, T_max=T, eta_min=cfg.min_lr)
+        opt2.load_state_dict(sd)
+        sch2.load_state_dict(ssd)
+        opt.step(); sch.step(); opt2.step(); sch2.step()
+        for a, b in zip(sch.get_last_lr(), sch2.get_last_lr()):
+            assert abs(a - b) <= 1e-9 * a
+    finally:
+        tr.reducer.close()

@@ -624,6 +624,26 @@ def test_cross_entropy(rows, V):
         assert acc2[1].item() == acc[1].item()
 
 
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_cross_entropy_nan_row_reaches_the_loss(bad):
+    """engine:315 raises on a NaN loss: a row with a NaN / inf logit must make loss_sum NaN (the ordered row sum
+    once clamped it away through fmaxf and counted the row as a zero-loss row)."""
+    rows, V = 24, 1024
+    logits = rnd(rows, V, seed=79, scale=2.0)
+    logits[7, 100] = bad
+    tgt = torch.arange(rows, dtype=torch.int32, device=DEV)
+    tgt[3] = -100
+    acc = torch.zeros(2, device=DEV)
+    ops.cross_entropy(logits, tgt, acc, None)
+    assert torch.isnan(acc[0]).item()
+    assert acc[1].item() == rows - 1                           # the NaN row is still a counted row
+    logits[7, 100] = 0.0                                       # and an ignored row with a NaN stays ignored
+    logits[3, 5] = bad
+    acc = torch.zeros(2, device=DEV)
+    ops.cross_entropy(logits, tgt, acc, None)
+    assert torch.isfinite(acc[0]).item() and acc[1].item() == rows - 1
+
+
 def test_sumsq_adamw_f32tobf16():
     n = 100003
     p, g = rnd(n, seed=81), rnd(n, seed=82, scale=0.1)

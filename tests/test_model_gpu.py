@@ -396,6 +396,29 @@ def test_nan_loss_is_reported_without_a_per_step_sync():
         w.flush()
 
 
+def test_forward_raises_on_nan_logits():
+    """ref engine:315-316: `if loss.sum().isnan(): raise ValueError`.  A NaN anywhere in the labelled rows' logits
+    must come out of the ordered cross-entropy sum as a NaN loss (it was once clamped to a zero-loss row)."""
+    from tests.helpers import build_model, make_cfg
+    from zero_amd.configs.zero.train_llama import func_optim_filter
+    from zero_amd.methods.engine_ar_instruction_llama import forward_from_ids
+    spec = GOLDEN_CONFIGS["tiny"]
+    enc, dec = spec["enc"], spec["dec"]
+    params = zo.make_params(enc, dec, spec["seed"], surrogate=True)
+    imgs, ids, tgts, img_id, pad_id = zo.synth_batch(enc, dec, **spec["batch"])
+    cfg = make_cfg(enc, dec, DEV, spec["ft_after"], spec["max_seq_len"])
+    cfg.check_nan_loss = "sync"
+    model = build_model(cfg, params)
+    func_optim_filter(cfg, model)
+    dimgs = [i.to(DEV).to(torch.bfloat16) for i in imgs]
+    loss = forward_from_ids(model, cfg, dimgs, ids, tgts, img_id, pad_id)
+    assert torch.isfinite(loss).item()
+    with torch.no_grad():
+        model.decoder.model.norm.weight[3] = float("nan")      # every logit row picks it up
+    with pytest.raises(ValueError, match="NaN"):
+        forward_from_ids(model, cfg, dimgs, ids, tgts, img_id, pad_id)
+
+
 def test_trainable_dgrad_transposed_copy_is_refreshed():
     """Large-M dgrad through a trainable weight uses a per-step transposed copy (functional.dgrad_trainable):
     same product as the copy-free path, and the copy follows the weights — through autograd's version counter

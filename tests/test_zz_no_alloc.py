@@ -74,3 +74,25 @@ def test_static_scratch_entry_rejects_oversize():
     assert rc == -7
     torch.cuda.synchronize()
     assert torch.count_nonzero(out) == 0
+
+
+def test_static_scratch_entry_reports_bad_arguments_before_the_size_limit():
+    """An invalid AND oversized call is an invalid call: -22 (null pointer, Hq not a multiple of Hkv, short row
+    stride), not -7; nothing is launched either way."""
+    from zero_amd._lib import lib
+    B, Hq, Hkv, hd = 4, 64, 8, 128
+    pos = 70000
+    qkv, kc, vc, cos_t, sin_t = _case(B, Hq, Hkv, hd, 8, 0, seed=9)
+    out = torch.zeros((B, Hq * hd), dtype=torch.bfloat16, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def call(qkv_p=qkv.data_ptr(), hkv=Hkv, ldqkv=qkv.stride(0)):
+        return lib.zk_attn_decode_fused_static(qkv_p, cos_t[0].data_ptr(), sin_t[0].data_ptr(), kc.data_ptr(),
+                                               vc.data_ptr(), out.data_ptr(), B, Hq, hkv, hd, ldqkv, out.stride(0),
+                                               pos + 1, pos, hd ** -0.5, st)
+    assert call() == -7
+    assert call(qkv_p=None) == -22
+    assert call(hkv=7) == -22
+    assert call(ldqkv=8) == -22
+    torch.cuda.synchronize()
+    assert torch.count_nonzero(out) == 0

@@ -985,13 +985,24 @@ extern "C" int zk_attn_decode_fused_static(const void* qkv, const float* cos_row
                                            void* v_cache, void* out, int64_t B, int64_t Hq, int64_t Hkv,
                                            int64_t head_dim, int64_t ldqkv, int64_t ldo, int64_t cache_rows,
                                            int64_t pos, float scale, hipStream_t stream) {
-  if (B <= 0 || Hq <= 0 || pos < 0 || (head_dim != 64 && head_dim != 128)) return ZK_EINVAL;
+  // argument errors first (-22), then the size limit (-7): an invalid AND oversized call is an invalid call
+  if (!qkv || !cos_row || !sin_row || !k_cache || !v_cache || !out) return ZK_EINVAL;
+  if (B <= 0 || B > 65535 || Hq <= 0 || Hkv <= 0 || Hkv > 65535 || Hq % Hkv || Hq / Hkv > 16) return ZK_EINVAL;
+  if ((head_dim != 64 && head_dim != 128) || pos < 0 || pos >= cache_rows || (ldqkv & 7)) return ZK_EINVAL;
+  if (ldqkv < (Hq + 2 * Hkv) * head_dim || ldo < Hq * head_dim) return ZK_EINVAL;
   const int64_t nchunks = pos / 64 + 1;
   // reject what does not fit BEFORE touching the device (no silent truncation; -7 = argument list too big)
-  if (B > ZK_ATTN_DECODE_STATIC_FLOATS || Hq > ZK_ATTN_DECODE_STATIC_FLOATS ||
-      B * Hq > ZK_ATTN_DECODE_STATIC_FLOATS / (head_dim + 2) ||
+  if (B * Hq > ZK_ATTN_DECODE_STATIC_FLOATS / (head_dim + 2) ||
       nchunks > ZK_ATTN_DECODE_STATIC_FLOATS / ((head_dim + 2) * B * Hq))
     return ZK_E2BIG;
+  // the array's address is per device: the CURRENT device must be the one `stream` belongs to (the kernels run
+  // there); a stream of another GPU would be handed this GPU's address
+  if (stream) {
+    hipDevice_t sdev = -1;
+    int cur = -1;
+    if (hipStreamGetDevice(stream, &sdev) != hipSuccess || hipGetDevice(&cur) != hipSuccess || (int)sdev != cur)
+      return ZK_EINVAL;
+  }
   float* ws = nullptr;
   const int rc = scratch_for_current_device(&ws);
   if (rc != ZK_OK) return rc;

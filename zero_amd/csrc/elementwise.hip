@@ -263,8 +263,9 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const bf16_t* logits
   s = (m == -INFINITY) ? 0.f : s * __expf(m - gm);
   const float gs = block_sum(s, red);
   if (threadIdx.x == 0) {
-    const float l = logf(gs) + gm - xt;      // >= 0 up to rounding; clamped so that -1 can mark ignored rows
-    if (row_loss) row_loss[row] = fmaxf(l, 0.f);
+    const float l = logf(gs) + gm - xt;      // >= 0 up to rounding; clamped so that -1 can mark ignored rows.
+    // NOT fmaxf: it returns the non-NaN operand, and a NaN / inf row must reach the loss (ref engine:315 raises on it)
+    if (row_loss) row_loss[row] = (l < 0.f) ? 0.f : l;
     else { atomicAdd(loss_sum, l); atomicAdd(loss_sum + 1, 1.0f); }
   }
   if (dx) {
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(const float* row_loss, f
   float l = 0.f, c = 0.f;
   for (int r = threadIdx.x; r < rows; r += 256) {
     const float v = row_loss[r];
-    if (v >= 0.f) { l += v; c += 1.0f; }
+    if (v != -1.0f) { l += v; c += 1.0f; }     // -1 = ignored row; a NaN row compares unequal and is added
   }
   sl[threadIdx.x] = l; sc[threadIdx.x] = c;
   __syncthreads();

@@ -1122,6 +1122,14 @@ int splitk_choice(int64_t tiles, int64_t M, int64_t N, int64_t K, bool transpose
   return best;
 }
 
+// persistent ring: byte offsets from the matrix base are 32-bit, and the epilogue must be one of its classes
+bool pring_fits(int64_t M, int64_t N, int64_t lda, int64_t ldb, int epilogue) {
+  const bool cls = epilogue == ZK_EPI_NONE || epilogue == ZK_EPI_QUICK_GELU || epilogue == ZK_EPI_MUL_DQUICK_GELU ||
+                   epilogue == ZK_EPI_SWIGLU || epilogue == ZK_EPI_SWIGLU_BWD || epilogue == ZK_EPI_GELU_ERF ||
+                   epilogue == ZK_EPI_MUL_DGELU_ERF;
+  return cls && (M + 64) * lda * 2 < 0x7FFFFFF0LL && (N + 64) * ldb * 2 < 0x7FFFFFF0LL;
+}
+
 // Tile choice: time ~ rounds(tiles / concurrent blocks) x tile area / relative efficiency.
 int choose_tile(int64_t M, int64_t N, int64_t K, int transA, int transB, bool need_tn4, const Plan& P) {
   const bool nt_ring = !transA && !transB && P.ring;
@@ -1251,7 +1259,11 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
     ZK_CHECK_LAUNCH();
     return ZK_OK;
   }
-  const int tile = choose_tile(M, N, K, transA, transB, epilogue == ZK_EPI_SWIGLU, P);
+  int tile = choose_tile(M, N, K, transA, transB, epilogue == ZK_EPI_SWIGLU, P);
+  // the 192x256 tile exists on the persistent ring only, which needs whole-matrix 32-bit byte offsets (operands
+  // under 2 GiB) and one of its epilogue classes: anything else runs as the 256x256 tile, whose one-workgroup-per-
+  // tile ring / two-stage kernels take every shape (a plain zk_gemm_bf16 call must not fail on a tile choice)
+  if (tile == 5 && !pring_fits(M, N, lda, ldb, epilogue)) tile = 2;
   g_last_plan = tile * 100;            // plain two-stage kernel unless a ring variant takes over below
   switch (tile) {
     case 3: launch_cfg<128, 96, 2, 2>(g, transA, transB, stream, P); break;
@@ -1303,7 +1315,7 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
 #undef ZK_PRING
           break;
         }
-        if (tile == 5) return ZK_EINVAL;   // (choose_tile only returns 5 when the persistent ring's conditions hold)
+        if (tile == 5) return ZK_EINVAL;   // unreachable: tile 5 was turned into tile 2 above unless the ring's conditions hold (forced ablation modes aside)
         g_last_plan = 2000 + tile * 100 + (lean ? 10 : 0);
 #define ZK_RINGX(MODE_) \
   do { \

@@ -32,7 +32,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from ..functional import GradSink
+from ..functional import SinkState
 from .comm import TorchComm
 
 _DEBUG = os.environ.get("ZERO_AMD_DDP_DEBUG") == "1"
@@ -87,6 +87,8 @@ class FlatGradReducer:
         if not named:
             raise ValueError("no trainable parameters: call func_optim_filter before building the reducer")
         self.names = {id(p): n for n, p in named}
+        # this replica's gradient-sink state (functional.GradSink finds it through the parameters)
+        self.sink = SinkState(on_grad=self._on_grad)
         ordered = [p for _, p in reversed(named)]                 # gradient-ready order
         groups = _pack_groups(ordered)
         self.params: List[nn.Parameter] = [p for g in groups for p in g]
@@ -106,6 +108,7 @@ class FlatGradReducer:
                 p.data = self.flat_param[o:o + n].view(p.shape)
                 p._zk_grad = self.flat_grad[o:o + n]
                 p._zk_dirty = False
+                p._zk_sink = self.sink
                 self.offset[id(p)] = o
         if self.world > 1:
             # DDP's _sync_module_states: every replica starts from rank 0's trainable parameters
@@ -127,7 +130,6 @@ class FlatGradReducer:
         self._handles: List = []
         self._sync = True
         self._launched = [False] * len(self.buckets)
-        GradSink.listeners.append(self._on_grad)
         self.begin_step()
 
     # ---- step protocol ---------------------------------------------------------------
@@ -205,8 +207,9 @@ class FlatGradReducer:
         return 1.0 / self.world                                   # DDP averages
 
     def close(self):
-        if self._on_grad in GradSink.listeners:
-            GradSink.listeners.remove(self._on_grad)
+        self.sink.on_grad = None
         for p in self.params:
             if hasattr(p, "_zk_grad"):
                 del p._zk_grad
+            if getattr(p, "_zk_sink", None) is self.sink:
+                del p._zk_sink

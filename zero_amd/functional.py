@@ -12,6 +12,7 @@ from __future__ import annotations
 from typing import List, Optional, Tuple
 
 import os
+import threading
 
 import torch
 
@@ -44,12 +45,24 @@ class ZeroArena:
         return self.buf[start:start + n]
 
 
-class GradSink:
-    """Routes a parameter gradient either into its flat-buffer slot or back to autograd."""
+class SinkState:
+    """What one gradient owner (a FlatGradReducer, i.e. one Trainer replica) keeps for its slots: the fp32 arena of
+    the vector gradients' partial sums, the conversions queued by the running backward node, and the callback
+    fired when a slot has received its gradient.  Reached through the PARAMETER (``p._zk_sink``), never through
+    process-wide state: two Trainers in one process (the rank-thread DDP harness) keep separate queues."""
 
-    listeners = []          # callables(param) fired when a slot has received its gradient
-    arena: Optional[ZeroArena] = None   # set by the Trainer for the duration of its life
-    pending = []            # (fp32 accumulator, bf16 slot, accumulate, param): converted by flush()
+    def __init__(self, on_grad=None, arena: Optional[ZeroArena] = None):
+        self.on_grad = on_grad
+        self.arena = arena
+        self.pending = []       # (fp32 accumulator, bf16 slot, accumulate, param): converted by GradSink.flush()
+
+
+class GradSink:
+    """Routes a parameter gradient either into its flat-buffer slot or back to autograd.  A layer node's backward
+    calls ``bind(params...)`` first: the SinkState of its parameters becomes the node's current one (thread-local:
+    a node runs start to end on one autograd thread) until ``flush()`` ends the node."""
+
+    _tls = threading.local()
 
     @staticmethod
     def slot(p: torch.Tensor) -> Optional[torch.Tensor]:
@@ -60,15 +73,42 @@ class GradSink:
         return getattr(p, "_zk_dirty", False)
 
     @staticmethod
+    def bind(*params):
+        cur = None
+        for p in params:
+            st = getattr(p, "_zk_sink", None) if p is not None else None
+            if st is not None:
+                if cur is not None and st is not cur:
+                    raise RuntimeError("one layer's parameters belong to two gradient owners")
+                cur = st
+        GradSink._tls.cur = cur
+
+    @staticmethod
+    def _cur() -> Optional[SinkState]:
+        return getattr(GradSink._tls, "cur", None)
+
+    @staticmethod
     def done(p):
         p._zk_dirty = True
-        for fn in GradSink.listeners:
-            fn(p)
+        st = getattr(p, "_zk_sink", None)
+        if st is not None and st.on_grad is not None:
+            st.on_grad(p)
+
+    @staticmethod
+    def queue(parts_f32, slot, p):
+        st = p._zk_sink
+        cur = GradSink._cur()
+        if cur is None:
+            GradSink._tls.cur = st
+        elif cur is not st:
+            raise RuntimeError("a vector gradient was queued for another owner than the node is bound to")
+        st.pending.append((parts_f32, slot, GradSink.is_dirty(p), p))
 
     @staticmethod
     def parts(nparts: int, n: int, device) -> torch.Tensor:
         """Uninitialised fp32 [nparts, n] slab for one vector gradient's partial sums."""
-        a = GradSink.arena
+        cur = GradSink._cur()
+        a = cur.arena if cur is not None else None
         if a is not None and a.buf.device == torch.device(device):
             t = a.take(nparts * n)
             if t is not None:
@@ -77,15 +117,19 @@ class GradSink:
 
     @staticmethod
     def flush():
-        """One conversion launch for every vector gradient queued since the last flush (called at the
-        end of each layer node's backward), then the slot notifications."""
-        if GradSink.pending:
-            batch, GradSink.pending = GradSink.pending, []
+        """One conversion launch for every vector gradient queued by this node (called at the end of each
+        layer node's backward), then the slot notifications; ends the node's binding."""
+        cur = GradSink._cur()
+        GradSink._tls.cur = None
+        if cur is None:
+            return
+        if cur.pending:
+            batch, cur.pending = cur.pending, []
             ops.f32_to_bf16_multi_([(a, s_, acc) for a, s_, acc, _ in batch])
             for _, _, _, p in batch:
                 GradSink.done(p)
-        if GradSink.arena is not None:
-            GradSink.arena.reset()       # stream-ordered: the next layer's kernels run after this conversion
+        if cur.arena is not None:
+            cur.arena.reset()            # stream-ordered: the next layer's kernels run after this conversion
 
 
 # ------------------------------------------------------------------------------------------
@@ -202,7 +246,7 @@ def _vec_grad(parts_f32: torch.Tensor, p: torch.Tensor, need: bool):
         return None
     slot = GradSink.slot(p)
     if slot is not None:
-        GradSink.pending.append((parts_f32, slot, GradSink.is_dirty(p), p))   # summed + converted by GradSink.flush()
+        GradSink.queue(parts_f32, slot, p)       # summed + converted by GradSink.flush()
         return None
     out = torch.empty(p.shape, dtype=BF16, device=p.device)
     ops.f32_to_bf16_multi_([(parts_f32, out.view(-1), False)])
@@ -267,6 +311,7 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, w, b, pre = ctx.saved_tensors
+        GradSink.bind(w, b)
         dy2 = dy.reshape(-1, dy.shape[-1])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
@@ -295,6 +340,7 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, gamma, beta, mean, rstd = ctx.saved_tensors
+        GradSink.bind(gamma, beta)
         dy2 = dy.reshape(x2.shape)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
@@ -374,6 +420,7 @@ class EncoderLayerFn(torch.autograd.Function):
     def backward(ctx, dy):
         (x2, mean1, rstd1, h1, qkv, ao, lse, xa, mean2, rstd2, h2, pre, act,
          l1w, l1b, qw, qb, kw, kb, vw, vb, ow, ob, l2w, l2b, f1w, f1b, f2w, f2b) = ctx.saved_tensors
+        GradSink.bind(l1w, l1b, qw, qb, kw, kb, vw, vb, ow, ob, l2w, l2b, f1w, f1b, f2w, f2b)
         B, T, D, heads, hd = ctx.dims
         M = B * T
         nig = ctx.needs_input_grad
@@ -504,6 +551,7 @@ class DecoderLayerFn(torch.autograd.Function):
     def backward(ctx, dy):
         (x2, rstd1, qkv, ao, lse, xa, rstd2, gu, l1w, qw, kw, vw, ow, l2w, gw, uw, dw, cos_t, sin_t,
          h1, h2, hm) = ctx.saved_tensors
+        GradSink.bind(l1w, qw, kw, vw, ow, l2w, gw, uw, dw)
         B, S, d, nh, nkv, hd, F = ctx.dims
         M = B * S
         nig = ctx.needs_input_grad
@@ -578,6 +626,7 @@ class AdapterFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, pre, act, w0, b0, w2, b2 = ctx.saved_tensors
+        GradSink.bind(w0, b0, w2, b2)
         nig = ctx.needs_input_grad
         dy2 = dy.reshape(-1, dy.shape[-1])
         if not dy2.is_contiguous():
@@ -620,6 +669,7 @@ class SpliceFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         inv_codes, soi_pos, eoi_pos, soi, eoi = ctx.saved_tensors
+        GradSink.bind(soi, eoi)
         d = ctx.d
         dy2 = dy.reshape(-1, d)
         if not dy2.is_contiguous():

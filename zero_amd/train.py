@@ -18,7 +18,7 @@ import torch.nn as nn
 from . import ops
 from .distributed.comm import use_comm
 from .distributed.ddp import FlatGradReducer
-from .functional import GradSink, ZeroArena, bump_weights_epoch
+from .functional import ZeroArena, bump_weights_epoch
 
 
 class Trainer:
@@ -35,6 +35,7 @@ class Trainer:
         self.v = torch.zeros(r.numel, dtype=torch.float32, device=dev)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.arena = ZeroArena(dev)             # per-backward fp32 accumulators of the vector gradients
+        r.sink.arena = self.arena               # this replica's own (functional.SinkState): nothing process-wide
         # (lr, wd) per parameter from the reference-style groups, merged into contiguous segments
         hp = {}
         for g in optim_groups:
@@ -66,6 +67,18 @@ class Trainer:
         t = min(step, self.total_steps)
         return 0.5 * (1 + math.cos(math.pi * t / max(1, self.total_steps)))
 
+    def current_lr(self, group_lr: float, step: int) -> float:
+        """The learning rate step ``step`` applies to a group whose base rate is ``group_lr``: linear warm-up, then
+        CosineAnnealingLR's closed form ``eta_min + (base - eta_min) (1 + cos(pi t / T_max)) / 2``.  The ONE place
+        the schedule is evaluated: the optimizer step, ``state_dict()['param_groups'][i]['lr']`` and the scheduler
+        view's ``_last_lr`` all come from here (torch's scheduler recurses on ``group['lr']``, so a checkpoint
+        must carry the rate that was really applied)."""
+        f = self.lr_factor(step)
+        if self.warmup_steps > 0 and step <= self.warmup_steps:
+            return group_lr * f
+        min_lr = float(getattr(self.cfg, "min_lr", 0.0))
+        return min_lr + (group_lr - min_lr) * f
+
     def micro_step(self, *fwd_args, **fwd_kwargs) -> torch.Tensor:
         """forward + backward of one micro-batch; the optimizer runs on the last one."""
         r = self.reducer
@@ -78,7 +91,6 @@ class Trainer:
         else:
             loss = self.forward(self.cfg, *fwd_args, **fwd_kwargs)         # train.py:524
         scaled = loss / self.accum                                          # train.py:527
-        GradSink.arena = self.arena
         self.arena.reset()
         if last:
             scaled.backward()                                               # train.py:567
@@ -88,7 +100,6 @@ class Trainer:
             with r.no_sync():                                               # train.py:562-564
                 scaled.backward()
                 r.finish_backward()
-        GradSink.arena = None
         self._micro += 1
         return loss.detach()
 
@@ -106,10 +117,8 @@ class Trainer:
         max_norm = float(cfg.grad_clip)
         if max_norm > 0:
             ops.sumsq_(r.flat_grad, self.sumsq, scale=r.grad_scale)         # clip_grad_norm_ (train.py:574-576)
-        f = self.lr_factor(self.global_step)
         for o, e, (lr, wd) in self.segments:
-            min_lr = float(getattr(cfg, "min_lr", 0.0))
-            cur = min_lr + (lr - min_lr) * f if self.global_step > self.warmup_steps else lr * f
+            cur = self.current_lr(lr, self.global_step)
             ops.adamw_step_(r.flat_param[o:e], r.flat_grad[o:e], self.m[o:e], self.v[o:e], lr=cur,
                             beta1=cfg.adamw_beta1, beta2=cfg.adamw_beta2, eps=1e-8, weight_decay=wd,
                             step=self.global_step, max_norm=max_norm, sumsq=self.sumsq, grad_scale=r.grad_scale)
@@ -125,7 +134,8 @@ class Trainer:
         moments are this Trainer's fp32 ones (torch casts them to the parameter dtype on load)."""
         r, cfg = self.reducer, self.cfg
         state, groups, i = {}, [], 0
-        f = self.lr_factor(self.global_step) if self.global_step > 0 else (0.0 if self.warmup_steps > 0 else 1.0)
+        lr_now = lambda base: (self.current_lr(base, self.global_step) if self.global_step > 0
+                               else (0.0 if self.warmup_steps > 0 else base))
         for g in self._groups:
             idx = []
             for p in g["params"]:
@@ -136,7 +146,7 @@ class Trainer:
                                 "exp_avg_sq": self.v[o:o + n].detach().to("cpu", copy=True).view(p.shape)}
                 idx.append(i)
                 i += 1
-            groups.append({"lr": g["lr"] * f, "initial_lr": g["lr"], "betas": (float(cfg.adamw_beta1), float(cfg.adamw_beta2)),
+            groups.append({"lr": lr_now(g["lr"]), "initial_lr": g["lr"], "betas": (float(cfg.adamw_beta1), float(cfg.adamw_beta2)),
                            "eps": 1e-8, "weight_decay": g["weight_decay"], "amsgrad": False, "maximize": False,
                            "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                            "decoupled_weight_decay": True, "params": idx})
@@ -189,7 +199,7 @@ class _SchedulerView:
         t = self.t
         return {"T_max": t.total_steps, "eta_min": float(getattr(t.cfg, "min_lr", 0.0)),
                 "base_lrs": [g["lr"] for g in t._groups], "last_epoch": t.global_step,
-                "_step_count": t.global_step + 1, "_last_lr": [g["lr"] * t.lr_factor(max(t.global_step, 1)) for g in t._groups]}
+                "_step_count": t.global_step + 1, "_last_lr": [t.current_lr(g["lr"], max(t.global_step, 1)) for g in t._groups]}
 
     def load_state_dict(self, sd: dict):
         self.t.global_step = int(sd["last_epoch"])
