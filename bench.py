@@ -125,6 +125,38 @@ def pmc_traffic(kernel: str):
         return None
 
 
+def self_launch(n: int, argv=None) -> int:
+    """`python bench.py --gpus N` without a launcher around it: run
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    <the same arguments>` as a child, pass its stderr through, print the one JSON line rank 0 wrote, return its exit
+    code.  ZERO_AMD_BENCH_LAUNCHER (a command prefix that replaces `python -m torch.distributed.run`) exists for the
+    CPU test of this path."""
+    import shlex
+    import socket
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    with socket.socket() as sk:                       # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    launcher = os.environ.get("ZERO_AMD_BENCH_LAUNCHER")
+    head = shlex.split(launcher) if launcher else [sys.executable, "-m", "torch.distributed.run"]
+    cmd = head + ["--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                  os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.lstrip().startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines[-1:]:
+            print(ln, file=sys.stderr)                  # anything else a rank printed is not the result
+    if lines:
+        print(lines[-1], flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the launcher exited 0 without a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
 def main():
     args = parse()
     if os.environ.get("ZERO_AMD_BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack and exit after N seconds
@@ -133,9 +165,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started the way the N = 1 case is (`python bench.py --gpus N`): start the ranks ourselves.  Nothing has
+        # touched the GPU yet, and the launcher is a CHILD process (never an exec): its one JSON line is relayed.
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch one rank per GPU")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or args.force_dist:
@@ -150,7 +185,7 @@ def main():
     if args.workload == "c5":
         return bench_c5(args, world, rank, device)
 
-    from oracle import zero_oracle as zo   # cpu_baseline leg + synthetic batch generator only
+    from zero_amd.synthetic import synth_batch
     from zero_amd import ops
     from zero_amd.build_decoder import load_hf_llama3
     from zero_amd.build_encoder import load_clip
@@ -198,10 +233,8 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(1337 + rank)
     n_pre, n_post, n_resp = 21, 168, 128
     T = (img_size // 14) ** 2 + 1
-    dcfg = zo.DecoderCfg(vocab=128256)
-    ecfg = zo.EncoderCfg()
-    imgs_cpu, ids, tgts, img_id, pad_id = zo.synth_batch(ecfg, dcfg, B, 1337 + rank, n_pre=n_pre, n_post=n_post,
-                                                         n_resp=n_resp)
+    imgs_cpu, ids, tgts, img_id, pad_id = synth_batch(img_size, 128256, B, 1337 + rank, n_pre=n_pre, n_post=n_post,
+                                                      n_resp=n_resp)
     imgs = [i.to(device).to(torch.bfloat16) for i in imgs_cpu]
     S = n_pre + (T + 2) + n_post
 
@@ -372,6 +405,8 @@ def main():
     # ---- CPU baseline: the oracle on the host cores, rank 0, N = 1 only, bounded sample
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "c2":
+        from oracle import zero_oracle as zo   # the checker, timed as the CPU baseline: this leg only
+        ecfg = zo.EncoderCfg()
         cores = os.cpu_count() or 1
         cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
         torch.set_num_threads(cores)
@@ -441,7 +476,6 @@ def bench_c5(args, world, rank, device):
     prefix, prefill of the 768-token prompt, then greedy decoding with a KV cache.  Each rank holds 1/W
     of every layer (distributed/tensor_parallel.py); with one GPU the rank-0 shard of a --tp split is
     built directly (same shapes, random init) and the all-reduces are skipped (compute-only number)."""
-    from oracle import zero_oracle as zo
     from zero_amd.build_encoder import load_clip
     from zero_amd.configs.config_base import LLAMA_SHAPES
     from zero_amd.configs.zero import train_llama as run_cfg
@@ -478,8 +512,8 @@ def bench_c5(args, world, rank, device):
     model = Zero(cfg, encoder, decoder)
     model.eval()
     tp = TPContext(rank, world, None) if world > 1 else TPContext()
-    imgs_cpu, ids, _, img_id, _ = zo.synth_batch(zo.EncoderCfg(), zo.DecoderCfg(vocab=128256), 1, 1337, n_pre=21,
-                                                 n_post=168, n_resp=1)
+    from zero_amd.synthetic import synth_batch
+    imgs_cpu, ids, _, img_id, _ = synth_batch(336, 128256, 1, 1337, n_pre=21, n_post=168, n_resp=1)
     imgs = [i.to(device).to(torch.bfloat16) for i in imgs_cpu]
     nl, kvw = len(decoder.model.layers), lcfg.num_key_value_heads * lcfg.head_dim
     wte = decoder.model.get_input_embeddings()

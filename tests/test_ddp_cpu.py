@@ -50,9 +50,24 @@ def _worker(rank, world, port, q):
                 self.q, self.k, self.v = Linear(8, 8), Linear(8, 8), Linear(8, 8)
                 pack_params([self.q.weight, self.k.weight, self.v.weight])
                 self.o = Linear(8, 16)
+                self.frozen = Linear(8, 4)                  # not trainable: DDP syncs it all the same
+                self.frozen.weight.requires_grad_(False)
+                self.frozen.bias.requires_grad_(False)
+                self.register_buffer("table", torch.randn(5))
         torch.manual_seed(100 + rank)                       # replicas seeded DIFFERENTLY on purpose
         m = M()
+        # replicas whose frozen tensors differ: "checksum" refuses them, "broadcast" (the default) repairs them
+        try:
+            FlatGradReducer(m, bucket_bytes=256, sync_frozen="checksum").close()
+            raised = False
+        except RuntimeError as e:
+            raised = "frozen" in str(e)
+        assert raised, "differently seeded frozen tensors went unnoticed"
         r = FlatGradReducer(m, bucket_bytes=256)
+        for t in (m.frozen.weight, m.frozen.bias, m.table):
+            both_f = [torch.empty_like(t.data) for _ in range(2)]
+            dist.all_gather(both_f, t.data.clone())
+            assert torch.equal(both_f[0], both_f[1]), "frozen tensors differ after construction"
         assert r.world == 2 and len(r.buckets) >= 2
         params = list(r.params)
         # construction broadcast rank 0's parameters (DDP's _sync_module_states, ref:train.py:367)
@@ -130,6 +145,7 @@ def _worker(rank, world, port, q):
                 write(p, 1.0, False)
         r.finish_backward()
         r.close()
+        FlatGradReducer(m, bucket_bytes=256, sync_frozen="checksum").close()   # frozen tensors identical now: passes
         dist.destroy_process_group()
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001

@@ -76,7 +76,8 @@ def _pack_groups(params: List[nn.Parameter]) -> List[List[nn.Parameter]]:
 
 
 class FlatGradReducer:
-    def __init__(self, model: nn.Module, bucket_bytes: int = 25 * 1024 * 1024, process_group=None, comm=None):
+    def __init__(self, model: nn.Module, bucket_bytes: int = 25 * 1024 * 1024, process_group=None, comm=None,
+                 sync_frozen: str = "broadcast"):
         self.comm = comm if comm is not None else TorchComm(process_group)     # RCCL unless a test passes its own
         self.pg = process_group
         self.world = self.comm.world
@@ -111,8 +112,12 @@ class FlatGradReducer:
                 p._zk_sink = self.sink
                 self.offset[id(p)] = o
         if self.world > 1:
-            # DDP's _sync_module_states: every replica starts from rank 0's trainable parameters
+            # DDP's _sync_module_states (ref:train.py:367): every replica starts from rank 0's parameters AND
+            # buffers — the trainable ones in one flat broadcast, the frozen ones (the surrogate decoder, encoder
+            # layers 0-15: replicas seeded differently or loaded from different partial checkpoints would train on
+            # different functions without any error) tensor by tensor, or verified by a checksum
             self.comm.broadcast(self.flat_param, src=0)
+            self._sync_frozen(model, sync_frozen)
         # contiguous buckets
         self.buckets: List[dict] = []
         cur = dict(start=0, end=0, params=[])
@@ -131,6 +136,59 @@ class FlatGradReducer:
         self._sync = True
         self._launched = [False] * len(self.buckets)
         self.begin_step()
+
+    def _sync_frozen(self, model: nn.Module, mode: str):
+        """mode "broadcast": rank 0's frozen parameters and buffers overwrite everyone's (what DDP does);
+        "checksum": nothing is moved, but replicas whose frozen tensors differ raise (4.4-10 GB less traffic at
+        start-up when every rank loaded the same checkpoint); "off": trust the caller."""
+        if mode not in ("broadcast", "checksum", "off"):
+            raise ValueError(f"sync_frozen = {mode!r}")
+        if mode == "off":
+            return
+        mine = {id(p) for p in self.params}
+        seen, frozen = set(), []
+        for n, t in list(model.named_parameters()) + list(model.named_buffers()):
+            key = (t.untyped_storage().data_ptr(), t.storage_offset(), t.numel())
+            if id(t) in mine or t.numel() == 0 or key in seen:       # tied weights: once
+                continue
+            seen.add(key)
+            frozen.append((n, t))
+        if mode == "broadcast":
+            with torch.no_grad():
+                for n, t in frozen:
+                    d = t.data
+                    if d.is_contiguous():
+                        self.comm.broadcast(d, src=0)
+                    else:
+                        c = d.contiguous()
+                        self.comm.broadcast(c, src=0)
+                        d.copy_(c)
+                    # layouts derived from a frozen weight (functional._frozen_t / _frozen_gate_up) follow the
+                    # weight: drop whatever was built before the broadcast
+                    for k in ("_zk_wt", "_zk_gu"):
+                        t.__dict__.pop(k, None)
+            return
+        # checksum: per tensor an order-independent fp64 sum of the raw bit patterns read as integers (exact for
+        # any size this path has: 2^16 * 2^33 elements < 2^53), all in ONE all-reduce of [sum_r0-weighted, sum]
+        sums = []
+        for n, t in frozen:
+            d = t.detach()
+            if d.dtype in (torch.bfloat16, torch.float16):
+                bits = d.contiguous().view(torch.int16).to(torch.float64)
+            elif d.dtype == torch.float32:
+                bits = d.contiguous().view(torch.int32).to(torch.float64)
+            else:
+                bits = d.to(torch.float64)
+            sums.append(bits.sum())
+        local = torch.stack(sums) if sums else torch.zeros(0, dtype=torch.float64, device=self.flat_param.device)
+        ref = local.clone()
+        self.comm.broadcast(ref, src=0)
+        bad = (ref != local).to(torch.float64)
+        self.comm.all_reduce(bad)
+        if bool(bad.sum() > 0):
+            names = [frozen[i][0] for i in torch.nonzero(bad.cpu()).flatten().tolist()[:8]]
+            raise RuntimeError(f"frozen tensors differ between replicas (first: {names}): load the same checkpoint on "
+                               "every rank or construct the reducer with sync_frozen='broadcast'")
 
     # ---- step protocol ---------------------------------------------------------------
     def begin_step(self):

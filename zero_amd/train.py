@@ -24,11 +24,12 @@ from .functional import ZeroArena, bump_weights_epoch
 class Trainer:
     def __init__(self, cfg, model: nn.Module, forward_fn: Callable, optim_groups: List[dict], *,
                  total_steps: int = 1000, warmup_steps: int = 0, process_group=None, bucket_bytes=25 << 20,
-                 comm=None):
+                 comm=None, sync_frozen: str = "broadcast"):
         self.cfg, self.model = cfg, model
         self.forward = forward_fn.__get__(model, model.__class__)          # train.py:213-214
         self.comm = comm             # None: torch.distributed (RCCL); tests pass a rank-thread communicator
-        self.reducer = FlatGradReducer(model, bucket_bytes=bucket_bytes, process_group=process_group, comm=comm)
+        self.reducer = FlatGradReducer(model, bucket_bytes=bucket_bytes, process_group=process_group, comm=comm,
+                                       sync_frozen=sync_frozen)
         r = self.reducer
         dev = r.flat_param.device
         self.m = torch.zeros(r.numel, dtype=torch.float32, device=dev)
