@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ZK_ABI_VERSION 4
+#define ZK_ABI_VERSION 5
 int zk_abi_version(void);
 
 /* ---- GEMM -------------------------------------------------------------------------
@@ -130,6 +130,15 @@ int zk_gemm_last_plan(void);
 int zk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B,
                 int64_t S, int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk,
                 int64_t ldv, int64_t ldo, float scale, int causal, hipStream_t stream);
+/* The same forward (same contract, same call sites replaced) on the long-sequence structure: one wave per SIMD,
+ * 64 query rows per wave as two 32-row halves that share every K / V fragment read, the softmax of one 32-key
+ * sub-tile placed between the MFMAs of its neighbours, O rescaled only when a row maximum grows by more than 2^8
+ * (results differ from zk_attn_fwd by rounding only).  Measured slower than zk_attn_fwd at the training step's
+ * S = 577 / 768 (one workgroup per CU leaves prologue and epilogue uncovered) and within 7 % of it at S >= 3072
+ * (DESIGN.md §4.2): zk_attn_fwd stays the step's kernel, this entry exists for tests and benchmarks. */
+int zk_attn_fwd_w64(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B,
+                    int64_t S, int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk,
+                    int64_t ldv, int64_t ldo, float scale, int causal, hipStream_t stream);
 int zk_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                 const float* lse, float* delta, void* dq, void* dk, void* dv, int64_t B,
                 int64_t S, int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk,

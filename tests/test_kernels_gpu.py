@@ -399,6 +399,58 @@ def test_attention_online_softmax_rescale_branch():
 
 
 @pytest.mark.parametrize("B,S,Hq,Hkv,hd,causal", [
+    (2, 577, 16, 16, 64, False),      # CLIP geometry: 2.25 query blocks of 256, last key tile crosses S
+    (1, 768, 24, 8, 128, True),       # Llama-3.2-3B geometry: 3 query blocks, diagonal tile = each wave's last
+    (2, 200, 6, 2, 128, True),        # ragged S inside one block, GQA rep 3, waves without rows
+    (1, 64, 2, 2, 64, False),         # a single key tile: first step is also the last
+    (1, 1, 4, 2, 128, False),
+    (3, 1300, 4, 2, 128, True),       # 21 key tiles: the steady-state loop
+    (2, 1100, 4, 4, 64, False),
+])
+def test_attention_fwd_w64_variant(B, S, Hq, Hkv, hd, causal):
+    """zk_attn_fwd_w64 (one wave per SIMD, 64 rows per wave, sub-tile pipelined softmax, thresholded rescale)
+    against the fp32 reference at the tolerance of zk_attn_fwd, and against zk_attn_fwd itself."""
+    W = (Hq + 2 * Hkv) * hd
+    qkv = rnd(B * S, W, seed=23)
+    q2, k2, v2 = qkv[:, :Hq * hd], qkv[:, Hq * hd:(Hq + Hkv) * hd], qkv[:, (Hq + Hkv) * hd:]
+    scale = hd ** -0.5
+    o, lse = ops.attn_fwd(q2, k2, v2, B, S, Hq, Hkv, hd, scale, causal, variant="w64")
+    o0, lse0 = ops.attn_fwd(q2, k2, v2, B, S, Hq, Hkv, hd, scale, causal)
+    qf = q2.float().reshape(B, S, Hq, hd).transpose(1, 2)
+    kf = k2.float().reshape(B, S, Hkv, hd).transpose(1, 2)
+    vf = v2.float().reshape(B, S, Hkv, hd).transpose(1, 2)
+    ro, rlse = ref_attention(qf, kf, vf, causal, scale)
+    ro2 = ro.transpose(1, 2).reshape(B * S, Hq * hd)
+    assert relerr(o, ro2) < 8e-3, "o"
+    assert (lse - rlse).abs().max().item() < 2e-3, "lse"
+    assert relerr(o, o0.float()) < 1e-2 and (lse - lse0).abs().max().item() < 2e-3     # two bf16 roundings apart
+
+
+def test_attention_fwd_w64_rescale_threshold_branch():
+    """The w64 kernel keeps a row's reference maximum until a tile raises it by more than 2^8; bounded random data
+    never takes that branch (nor the 'stale reference' path with p > 1), so both are forced: rows whose late keys
+    score 3, 7 and 40 units (log2 domain) above everything before, on the first and on later tiles, causal and not."""
+    B, H, hd = 1, 2, 128
+    for S, causal in ((512, False), (448, True)):
+        q = rnd(S, H * hd, seed=41) * 0.5
+        k = rnd(S, H * hd, seed=42) * 0.5
+        v = rnd(S, H * hd, seed=43)
+        # query rows 300.. get keys aligned with them: growth of the running maximum at key tiles 2, 3 and 4
+        for row, key, gain in ((300, 150, 3.0), (301, 210, 7.0), (302, 290, 40.0), (400, 100, 40.0), (401, 399, 12.0)):
+            qr = q[row, :hd].float()
+            k[key, :hd] = (qr / qr.norm() * gain * 0.6931 * hd ** 0.5 / qr.norm()).to(torch.bfloat16)
+        scale = hd ** -0.5
+        o, lse = ops.attn_fwd(q, k, v, B, S, H, H, hd, scale, causal, variant="w64")
+        qf = q.float().reshape(B, S, H, hd).transpose(1, 2)
+        kf = k.float().reshape(B, S, H, hd).transpose(1, 2)
+        vf = v.float().reshape(B, S, H, hd).transpose(1, 2)
+        ro, rlse = ref_attention(qf, kf, vf, causal, scale)
+        assert torch.isfinite(o.float()).all()
+        assert relerr(o, ro.transpose(1, 2).reshape(B * S, H * hd)) < 8e-3
+        assert (lse - rlse).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("B,S,Hq,Hkv,hd,causal", [
     (2, 200, 6, 2, 128, True),        # ragged S, GQA rep 3
     (1, 768, 24, 8, 128, True),       # Llama-3.2-3B geometry at S = 768
     (2, 130, 4, 2, 64, False),

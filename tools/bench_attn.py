@@ -5,6 +5,7 @@ import torch
 from zero_amd import ops
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+VARIANT = os.environ.get("ZERO_AMD_ATTN_VARIANT", "default")     # "w64": time zk_attn_fwd_w64 as the forward
 SHAPES = [("decoder causal", 8, 768, 24, 8, 128, True), ("encoder bidir ", 8, 577, 16, 16, 64, False)]
 if os.environ.get("ZERO_AMD_ATTN_SWEEP"):     # where the time goes: fixed cost per launch / block vs per tile
     SHAPES += [("causal S=1536", 8, 1536, 24, 8, 128, True), ("causal S=3072", 4, 3072, 24, 8, 128, True),
@@ -32,7 +33,7 @@ for name, B, S, Hq, Hkv, hd, causal in SHAPES:
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters
 
-    tf = timeit(lambda: ops.attn_fwd(q, k, v, B, S, Hq, Hkv, hd, scale, causal, out=o))
+    tf = timeit(lambda: ops.attn_fwd(q, k, v, B, S, Hq, Hkv, hd, scale, causal, out=o, variant=VARIANT))
     tb = timeit(lambda: ops.attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, S, Hq, Hkv, hd, scale, causal))
     print(f"{name} B={B} S={S} Hq={Hq} Hkv={Hkv} hd={hd}: fwd {tf*1e3:6.0f} us ({2*fl/tf/1e9:6.0f} TF)   "
           f"bwd {tb*1e3:6.0f} us ({7*fl/tb/1e9:6.0f} TF executed-7-products, {5*fl/tb/1e9:6.0f} TF algorithmic)", flush=True)

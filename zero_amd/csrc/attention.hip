@@ -22,74 +22,12 @@
 // dQ is produced by its own pass (recomputing S and dP) instead of fp32 atomics: it is
 // deterministic, and attention is < 3 % of the step's FLOPs.
 #include <atomic>
-#include "common.h"
+#include "attn_common.h"
 #include "../../include/zero_hip.h"
 
+using namespace zkattn;
+
 namespace {
-
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-struct AttnArgs {
-  const bf16_t *q, *k, *v, *o, *d_o;
-  bf16_t *out, *dq, *dk, *dv;
-  float* lse;
-  const float* lse_in;
-  const float* delta;
-  float* delta_out;
-  const float *cos_t, *sin_t;    // backward only: when set, dQ and dK leave with the inverse rotary applied
-  int B, S, Hq, Hkv;
-  int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
-  float scale;
-};
-
-template <int HD>
-struct Cfg {
-  static constexpr int CPR = HD / 8;         // 16-byte chunks per row
-  static constexpr int DS = HD / 16;         // k-steps over the head dim
-  static constexpr int DB = HD / 32;         // 32-wide d blocks
-};
-
-__device__ __forceinline__ bf16x8 pack_acc(const f32x16& a, int s) {
-  bf16x8 r;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * s + j];
-  return r;
-}
-__device__ __forceinline__ bf16x8 gfrag(const bf16_t* p, bool ok) {
-  if (!ok) { bf16x8 z;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f; return z; }
-  return *reinterpret_cast<const bf16x8*>(p);
-}
-// accumulator register r of lane-half h <-> tile row
-__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// ---- swizzled, unpadded LDS tiles (filled by LDS-DMA) --------------------------------------
-template <int HD>
-__device__ __forceinline__ int swz_key(int row) {
-  if (HD == 128) return ((row & 3) << 2) | ((row >> 2) & 3);
-  return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
-}
-template <int HD>
-__device__ __forceinline__ bf16x8 row_frag_sw(const unsigned char* lds, int row0, int ds, int lane) {
-  const int row = row0 + (lane & 31), chunk = ds * 2 + (lane >> 5);
-  return *reinterpret_cast<const bf16x8*>(lds + row * (HD * 2) + ((chunk ^ swz_key<HD>(row)) << 4));
-}
-template <int HD>
-__device__ __forceinline__ bf16x8 tr_frag_sw(const unsigned char* lds, int k0, int s, int db, int lane) {
-  const int h = lane >> 5, i = lane & 15;
-  const int row = k0 + 16 * s + 4 * h + (i >> 2);
-  const int chunk = db * 4 + 2 * ((lane >> 4) & 1) + ((i & 3) >> 1);
-  const int sub = (i & 1) * 8;
-  short4_t lo = lds_read_tr16(lds + row * (HD * 2) + ((chunk ^ swz_key<HD>(row)) << 4) + sub);
-  short4_t hi = lds_read_tr16(lds + (row + 8) * (HD * 2) + ((chunk ^ swz_key<HD>(row + 8)) << 4) + sub);
-  union { struct { short4_t a, b; } s2; bf16x8 v; } u;
-  u.s2.a = lo;
-  u.s2.b = hi;
-  return u.v;
-}
 
 // =========================================================================================
 // forward and dQ share the K/V stream: 64-key tiles (K rows then V rows, unpadded, chunk-swizzled,
@@ -1032,17 +970,29 @@ extern "C" int zk_attn_decode(const void* q, const void* k_cache, const void* v_
   return ZK_OK;
 }
 
-extern "C" int zk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B, int64_t S,
-                           int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv,
-                           int64_t ldo, float scale, int causal, hipStream_t stream) {
+namespace zkattn { int launch_attn_fwd_w64(const AttnArgs& a, int head_dim, int causal, hipStream_t stream); }
+namespace {
+int attn_fwd_args(AttnArgs& a, const void* q, const void* k, const void* v, void* o, float* lse, int64_t B, int64_t S,
+                  int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                  float scale) {
   if (!q || !k || !v || !o || bad_attn(B, S, Hq, Hkv, head_dim, ldq, ldk, ldv, ldo)) return ZK_EINVAL;
   // K / V rows of one batch element are addressed with 32-bit byte offsets by the LDS-DMA
   if (S * ldk * 2 >= 0x7FFFFFF0LL || S * ldv * 2 >= 0x7FFFFFF0LL) return ZK_EINVAL;
   if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) return ZK_EINVAL;
-  AttnArgs a{};
+  a = AttnArgs{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
   a.B = (int)B; a.S = (int)S; a.Hq = (int)Hq; a.Hkv = (int)Hkv;
   a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv; a.ldo = (int)ldo; a.scale = scale;
+  return ZK_OK;
+}
+}  // namespace
+
+extern "C" int zk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B, int64_t S,
+                           int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv,
+                           int64_t ldo, float scale, int causal, hipStream_t stream) {
+  AttnArgs a;
+  const int rc = attn_fwd_args(a, q, k, v, o, lse, B, S, Hq, Hkv, head_dim, ldq, ldk, ldv, ldo, scale);
+  if (rc != ZK_OK) return rc;
   dim3 grid((unsigned)(((S + 127) / 128) * Hq * B)), block(256);
   if (head_dim == 64) {
     if (causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, block, 0, stream, a);
@@ -1051,6 +1001,17 @@ extern "C" int zk_attn_fwd(const void* q, const void* k, const void* v, void* o,
     if (causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, block, 0, stream, a);
   }
+  ZK_CHECK_LAUNCH();
+  return ZK_OK;
+}
+
+extern "C" int zk_attn_fwd_w64(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B, int64_t S,
+                               int64_t Hq, int64_t Hkv, int64_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv,
+                               int64_t ldo, float scale, int causal, hipStream_t stream) {
+  AttnArgs a;
+  const int rc = attn_fwd_args(a, q, k, v, o, lse, B, S, Hq, Hkv, head_dim, ldq, ldk, ldv, ldo, scale);
+  if (rc != ZK_OK) return rc;
+  launch_attn_fwd_w64(a, (int)head_dim, causal, stream);
   ZK_CHECK_LAUNCH();
   return ZK_OK;
 }

@@ -194,8 +194,9 @@ def gemm_swiglu_bwd(dy: torch.Tensor, w_down_t: torch.Tensor, gu_i: torch.Tensor
 
 
 def attn_fwd(q, k, v, B: int, S: int, Hq: int, Hkv: int, hd: int, scale: float, causal: bool,
-             out: Optional[torch.Tensor] = None, need_lse: bool = True):
-    """q/k/v: [B*S, H*hd] row-strided views.  Returns (o [B*S, Hq*hd], lse [B,Hq,S] fp32 or None)."""
+             out: Optional[torch.Tensor] = None, need_lse: bool = True, variant: str = "default"):
+    """q/k/v: [B*S, H*hd] row-strided views.  Returns (o [B*S, Hq*hd], lse [B,Hq,S] fp32 or None).
+    variant "w64" = the 64-rows-per-wave kernel (zk_attn_fwd_w64: tests / benchmarks)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk2d(t, n)
     if q.shape != (B * S, Hq * hd) or k.shape != (B * S, Hkv * hd) or v.shape != (B * S, Hkv * hd):
@@ -204,8 +205,9 @@ def attn_fwd(q, k, v, B: int, S: int, Hq: int, Hkv: int, hd: int, scale: float, 
         out = torch.empty((B * S, Hq * hd), dtype=BF16, device=q.device)
     _chk2d(out, "out")
     lse = torch.empty((B, Hq, S), dtype=torch.float32, device=q.device) if need_lse else None
-    rc = lib.zk_attn_fwd(_p(q), _p(k), _p(v), _p(out), _p(lse), B, S, Hq, Hkv, hd, q.stride(0), k.stride(0),
-                         v.stride(0), out.stride(0), float(scale), int(causal), _stream())
+    fn = {"default": lib.zk_attn_fwd, "w64": lib.zk_attn_fwd_w64}[variant]
+    rc = fn(_p(q), _p(k), _p(v), _p(out), _p(lse), B, S, Hq, Hkv, hd, q.stride(0), k.stride(0),
+            v.stride(0), out.stride(0), float(scale), int(causal), _stream())
     check(rc, "zk_attn_fwd")
     return out, lse
 
