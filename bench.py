@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--gemm-shapes", action="store_true", help="per-shape GEMM table on stderr")
+    ap.add_argument("--gemm-gap", default="", metavar="FILE",
+                    help="after the instrumented steps, replay every distinct GEMM call of the step in isolation "
+                         "(same operands back to back = cache-hot; operands rotated through > 512 MB = cache-cold) "
+                         "and write the in-step / isolated table as JSON to FILE")
     ap.add_argument("--force-dist", action="store_true",
                     help="one-GPU rehearsal of the RCCL path: 1-rank process group, bucket all-reduces still issued")
     return ap.parse_args()
@@ -123,6 +127,63 @@ def pmc_traffic(kernel: str):
         return ent and ent["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         return None
+
+
+def gemm_gap_table(lib, calls, shp, path, device):
+    """Where the step's GEMM time goes relative to the same launches in isolation.  For every distinct GEMM call of
+    the instrumented steps: (a) its average duration INSIDE the step (HIP events around each launch), (b) the same
+    call replayed back to back on the same operands (everything it reads stays in L2 / the 256 MB Infinity Cache:
+    what tools/bench_gemm.py measures), (c) replayed with A and B rotated through copies that together exceed
+    512 MB (every launch reads its operands from HBM, as a weight that was last touched a step ago is read).
+    The activations the recorded pointers refer to have been recycled by then: the replays compute on whatever the
+    buffers hold now (timing only), and write into output buffers that nothing reads afterwards."""
+    rows = []
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def run(a, n_it, rot=None):
+        for it in range(3):
+            aa = a if rot is None else (rot[it % len(rot)] + a[2:])
+            lib.zk_gemm_bf16(*aa)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for it in range(n_it):
+            aa = a if rot is None else (rot[it % len(rot)] + a[2:])
+            lib.zk_gemm_bf16(*aa)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n_it * 1e3
+
+    for key, a in calls.items():
+        plan, (ta, tb), (M, N, K), epi = key
+        n_, ms_, fl = shp[key]
+        lda, ldb = a[6], a[7]
+        na = (K if ta else M) * lda
+        nb = (K if tb else N) * ldb
+        hot = run(a, 10)
+        copies = max(2, min(24, int(512e6 // ((na + nb) * 2)) + 1))
+        pool = []
+        for _ in range(copies):
+            ta_ = (torch.randn(na, device=device) * 0.5).to(torch.bfloat16)
+            tb_ = (torch.randn(nb, device=device) * 0.5).to(torch.bfloat16)
+            pool.append((ta_, tb_))
+        cold = run(a, max(10, copies), rot=[(x.data_ptr(), y.data_ptr()) for x, y in pool])
+        del pool
+        rows.append({"kernel": plan_name(plan), "transA": ta, "transB": tb, "M": M, "N": N, "K": K, "epilogue": epi,
+                     "launches_per_step": n_ // 2, "in_step_us": round(ms_ / n_ * 1e3, 1), "isolated_hot_us": round(hot, 1),
+                     "isolated_cold_us": round(cold, 1), "gflop": round(fl / 1e9, 1),
+                     "in_step_ms_per_step": round(ms_ / 2, 3),
+                     "ms_per_step_if_hot": round(hot * (n_ // 2) / 1e3, 3),
+                     "ms_per_step_if_cold": round(cold * (n_ // 2) / 1e3, 3)})
+    rows.sort(key=lambda r: -r["in_step_ms_per_step"])
+    tot = {k: round(sum(r[k] for r in rows), 2) for k in ("in_step_ms_per_step", "ms_per_step_if_hot", "ms_per_step_if_cold")}
+    with open(path, "w") as f:
+        json.dump({"total": tot, "rows": rows}, f, indent=1)
+    print(f"GEMM ms/step: in the step {tot['in_step_ms_per_step']}, same launches isolated cache-hot "
+          f"{tot['ms_per_step_if_hot']}, isolated cache-cold {tot['ms_per_step_if_cold']}", file=sys.stderr)
+    for r in rows[:24]:
+        print(f"  {r['kernel']:44s} tA{r['transA']}tB{r['transB']} epi{r['epilogue']} {r['M']:6d} {r['N']:6d} {r['K']:6d} "
+              f"x{r['launches_per_step']:3d}  in-step {r['in_step_us']:7.1f} us  hot {r['isolated_hot_us']:7.1f}  cold "
+              f"{r['isolated_cold_us']:7.1f}", file=sys.stderr)
 
 
 def self_launch(n: int, argv=None) -> int:
@@ -316,6 +377,7 @@ def main():
         # EVERY rank takes the two extra steps (they contain the step's collectives: a rank stepping
         # alone would wait for its peers forever); only rank 0 instruments its launches.
         records = []
+        calls = {}          # first call of every distinct (kernel, layout, shape, epilogue): replayed by --gemm-gap
 
         class _TimedLib:
             def __init__(self, real):
@@ -329,7 +391,9 @@ def main():
                 e0.record()
                 rc = self._real.zk_gemm_bf16(A, Bp, C, M, N, K, lda, ldb, ldc, ta, tb, epi, *rest)
                 e1.record()
-                records.append((self._real.zk_gemm_last_plan(), (ta, tb), 2.0 * M * N * K, e0, e1, (M, N, K), epi))
+                plan = self._real.zk_gemm_last_plan()
+                records.append((plan, (ta, tb), 2.0 * M * N * K, e0, e1, (M, N, K), epi))
+                calls.setdefault((plan, (ta, tb), (M, N, K), epi), (A, Bp, C, M, N, K, lda, ldb, ldc, ta, tb, epi) + rest)
                 return rc
 
         # the bandwidth-bound kernels of the same two steps, each launch bracketed the same way; algorithmic
@@ -376,6 +440,8 @@ def main():
             for (plan, tt, mnk, epi), (n_, ms_, fl) in sorted(shp.items(), key=lambda kv: -kv[1][1]):
                 print(f"  {plan_name(plan):46s} tA{tt[0]}tB{tt[1]} epi{epi} M,N,K={mnk}  x{n_ // 2:3d}/step  "
                       f"{ms_ / 2:7.2f} ms/step  {fl * n_ / (ms_ * 1e-3) / 1e12:7.1f} TF/s", file=sys.stderr)
+        if args.gemm_gap:
+            gemm_gap_table(real_lib, calls, shp, args.gemm_gap, device)
         key = max(fam, key=lambda k: fam[k]["ms"])
         d = fam[key]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12

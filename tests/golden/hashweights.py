@@ -51,8 +51,18 @@ def surrogate_shapes(enc: zo.EncoderCfg, dec: zo.DecoderCfg):
     return shapes
 
 
-def hash_params(enc: zo.EncoderCfg, dec: zo.DecoderCfg, seed: int, device, dtype=torch.bfloat16, only=None):
-    """Surrogate-model parameters (names as oracle.make_params(..., surrogate=True) gives them)."""
+_RESIDUAL_OUT = ("self_attn.o_proj.weight", "mlp.down_proj.weight", "self_attn.out_proj.weight", "mlp.fc2.weight")
+
+
+def hash_params(enc: zo.EncoderCfg, dec: zo.DecoderCfg, seed: int, device, dtype=torch.bfloat16, only=None,
+                init: str = "plain"):
+    """Surrogate-model parameters (names as oracle.make_params(..., surrogate=True) gives them).
+    init "conditioned": the output projection of every residual branch (o_proj / down_proj, out_proj / fc2) is
+    drawn 1 / sqrt(2 L) smaller (L = depth of its stack: the GPT-2 / Megatron scaled init), so the residual
+    stream keeps unit scale through the depth, the logits stay narrow and the loss starts near ln V — the regime a
+    trained model lives in, where bf16 arithmetic holds the 1e-2 class of tolerances."""
+    if init not in ("plain", "conditioned"):
+        raise ValueError(init)
     out = {}
     for name, shp in sorted(surrogate_shapes(enc, dec).items()):
         if only is not None and not only(name):
@@ -75,7 +85,11 @@ def hash_params(enc: zo.EncoderCfg, dec: zo.DecoderCfg, seed: int, device, dtype
             fan_in = 1
             for s_ in shp[1:]:
                 fan_in *= s_
-            t = z * max(0.02, 0.5 / math.sqrt(fan_in))
+            std = max(0.02, 0.5 / math.sqrt(fan_in))
+            if init == "conditioned" and name.endswith(_RESIDUAL_OUT):
+                depth = enc.layers if name.startswith("encoder.") else dec.surrogate_layers
+                std = std / math.sqrt(2.0 * depth)
+            t = z * std                          # (std is a Python float: still ONE fp32 multiply of z)
         out[name] = t.to(torch.bfloat16).to(dtype).view(shp)
     return out
 

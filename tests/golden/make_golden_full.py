@@ -5,6 +5,7 @@ Llama-3.1-8B surrogate; S = 768, V = 128256) through the REAL transformers modul
 
     python tests/golden/make_golden_full.py c3        (≈ 25 GB of RAM, a few minutes on 8 cores)
     python tests/golden/make_golden_full.py c4        (≈ 45 GB of RAM)
+    python tests/golden/make_golden_full.py c3c c4c   (the same models with the conditioned init, configs.FULL_CONFIGS)
 
 Purpose ("anchor the tolerances"): the bf16-vs-fp32 distance of transformers itself at full depth
 is the floor the HIP path's gradient tolerance is stated against (tests/test_fullsize_gpu.py).  Weights come
@@ -109,7 +110,7 @@ def run(name):
     spec = FULL_CONFIGS[name]
     enc, dec = spec["enc"], spec["dec"]
     t0 = time.time()
-    params = hash_params(enc, dec, spec["seed"], "cpu", dtype=torch.bfloat16)
+    params = hash_params(enc, dec, spec["seed"], "cpu", dtype=torch.bfloat16, init=spec.get("init", "plain"))
     out = {"weights_checksum": checksum(params)}
     print(name, "weights", f"{sum(v.numel() for v in params.values()) / 1e9:.2f} G params", f"{time.time() - t0:.0f} s",
           flush=True)

@@ -71,7 +71,7 @@ def _build(name):
         sys.stdout = stdout
     cfg.num_embd = num_embd
     model = Zero(cfg, encoder, decoder)
-    sd = hash_params(spec["enc"], spec["dec"], spec["seed"], DEV)
+    sd = hash_params(spec["enc"], spec["dec"], spec["seed"], DEV, init=spec.get("init", "plain"))
     chk = checksum(sd)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected and all(m == "decoder.lm_head.weight" for m in missing), (missing, unexpected)
@@ -93,6 +93,22 @@ def c3():
 def c4():
     cfg, model, chk = _build("c4")
     yield dict(cfg=cfg, model=model, chk=chk, spec=FULL_CONFIGS["c4"])
+    del model
+    torch.cuda.empty_cache()
+
+
+@pytest.fixture(scope="module")
+def c3c():
+    cfg, model, chk = _build("c3c")
+    yield dict(cfg=cfg, model=model, chk=chk, spec=FULL_CONFIGS["c3c"])
+    del model
+    torch.cuda.empty_cache()
+
+
+@pytest.fixture(scope="module")
+def c4c():
+    cfg, model, chk = _build("c4c")
+    yield dict(cfg=cfg, model=model, chk=chk, spec=FULL_CONFIGS["c4c"])
     del model
     torch.cuda.empty_cache()
 
@@ -215,6 +231,117 @@ def test_c4_reproducible_and_batch_additive(c4):
     # init 8B-width model whose gradients move 22 % (median) between transformers' own bf16 and fp32 runs: the same
     # identity holds to 1.5e-2 at C3 (tests/test_fullsize_gpu.py); embd_soi, a sum of 4 single rows, is the worst
     assert worst[1] <= 6e-2, worst
+
+
+# ------------------------------------------------------------------------------------------------------------
+# The contract's own numbers, without reference to a bf16 floor: the same full-width, full-depth models with the
+# conditioned init (loss near ln V = 11.76, narrow logits: the regime of a trained model).  north_star: logits and
+# losses "within a stated bf16 tolerance (e.g. max rel 1e-2), with encoder gradients compared under the same
+# tolerance".  Stated here: |loss - fp32| <= 1e-2; logits and inputs_embeds max-rel <= 2e-2 (max |a - b| / max |b|);
+# d(inputs_embeds) and EVERY trainable gradient Frobenius-relative <= 3e-2; gradient max-rel <= 3e-2 over all
+# tensors.  No `max(., floor)` escape: the transformers bf16-vs-fp32 distance of the fixture is printed beside
+# each figure for information only.
+# ------------------------------------------------------------------------------------------------------------
+def _golden_parity_strict(fx, gold):
+    spec = fx["spec"]
+    assert torch.equal(fx["chk"], gold["weights_checksum"]), "hash weights differ between the CPU fixture and this device"
+    imgs, ids, tgts, img_id, pad_id = zo.synth_batch(spec["enc"], spec["dec"], **spec["batch"])
+    loss, aux, grads = _step(fx, imgs, ids, tgts, img_id, pad_id, keep_inputs_grad=True)
+    assert int(aux["num_tokens"]) == int(gold["fp32.num_tokens"])
+    ref_loss = gold["fp32.loss"].item()
+    print("loss (hip, tf fp32, tf bf16)", loss.item(), ref_loss, gold["bf16.loss"].item())
+    assert ref_loss < 12.2, "the conditioned fixture must start near ln V = 11.76"
+    assert abs(loss.item() - ref_loss) <= 1e-2
+    e = maxrel(shrink(aux["inputs_embeds"].detach().cpu()), gold["fp32.inputs_embeds"])
+    print("inputs_embeds maxrel (hip, tf-bf16)", e, maxrel(gold["bf16.inputs_embeds"], gold["fp32.inputs_embeds"]))
+    assert e <= 2e-2
+    with torch.no_grad():
+        logits = fx["model"].decoder(inputs_embeds=aux["inputs_embeds"].detach(), use_cache=False)["logits"]
+    e = maxrel(shrink(logits.cpu()), gold["fp32.logits"])
+    e2 = maxrel(logits[0, gold["fp32.label_rows"].to(DEV), :256], gold["fp32.logits_label_rows"])
+    print("logits maxrel (hip, tf-bf16); label rows", e, maxrel(gold["bf16.logits"], gold["fp32.logits"]), e2,
+          maxrel(gold["bf16.logits_label_rows"], gold["fp32.logits_label_rows"]))
+    del logits
+    assert e <= 2e-2 and e2 <= 2e-2
+    e = frob(shrink(aux["inputs_embeds"].grad.detach().cpu()), gold["fp32.d_inputs_embeds"])
+    print("d_inputs_embeds frobenius (hip, tf-bf16)", e, frob(gold["bf16.d_inputs_embeds"], gold["fp32.d_inputs_embeds"]))
+    assert e <= 3e-2
+    names = [k[len("fp32.grad."):] for k in gold if k.startswith("fp32.grad.")]
+    assert set(names) == set(grads), set(names) ^ set(grads)
+    scale = max(gold["fp32.gradnorm." + n].item() / grads[n].numel() ** 0.5 for n in names)        # largest RMS
+    rows = []
+    for n in names:
+        g = grads[n]
+        sg, ref, tfb = shrink(g.detach().cpu()), gold["fp32.grad." + n], gold["bf16.grad." + n]
+        zero_floor = 1e-3 * scale * ref.numel() ** 0.5          # analytically-zero gradients (k_proj.bias)
+        e_f, fl_f = frob(sg, ref, zero_floor), frob(tfb, ref, zero_floor)
+        amax = max(gold["fp32.gradmax." + n].item(), 1e-3 * scale)
+        e_m = ((sg.float() - ref).abs().max() / amax).item()
+        nrm = abs(g.float().norm().item() - gold["fp32.gradnorm." + n].item()) / max(gold["fp32.gradnorm." + n].item(),
+                                                                                    1e-3 * scale * g.numel() ** 0.5)
+        rows.append((e_f, fl_f, e_m, nrm, n))
+    rows.sort(reverse=True)
+    print("worst gradients (frob hip, frob tf-bf16, maxrel hip, norm err, name)", rows[:5])
+    print("median frob (hip, tf-bf16)", sorted(r[0] for r in rows)[len(rows) // 2], sorted(r[1] for r in rows)[len(rows) // 2])
+    for e_f, fl_f, e_m, nrm, n in rows:
+        assert e_f <= 3e-2, ("frobenius", n, e_f, fl_f)
+        assert e_m <= 3e-2, ("max-rel", n, e_m)
+        assert nrm <= 2e-2, ("gradient norm", n, nrm)
+
+
+def test_c3_conditioned_init_against_transformers_golden_strict(c3c, golden_dir):
+    _golden_parity_strict(c3c, load_file(os.path.join(golden_dir, "full_c3c.safetensors")))
+
+
+def test_c4_conditioned_init_against_transformers_golden_strict(c4c, golden_dir):
+    _golden_parity_strict(c4c, load_file(os.path.join(golden_dir, "full_c4c.safetensors")))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# The BENCHED shape: B = 8 per GPU (M = 6144 decoder rows: the only M at which the 384 x 192 persistent ring and the
+# 192 x 256 / 256 x 256 SwiGLU pair are chosen; M = 4616 encoder rows).  The B = 1 step is pinned by the transformers
+# goldens above; the B = 8 step must equal the token-weighted sum of its eight B = 1 steps (loss_sum exactly
+# additive up to fp32 summation order, gradients to the tolerance two bf16 runs under different tilings keep).
+# Sample 0 of the eight IS the golden-pinned sample.
+# ------------------------------------------------------------------------------------------------------------
+def _batch8_equals_eight_singles(fx, tol):
+    spec = fx["spec"]
+    i0, d0, t0_, img_id, pad_id = zo.synth_batch(spec["enc"], spec["dec"], **spec["batch"])
+    i7, d7, t7, _, _ = zo.synth_batch(spec["enc"], spec["dec"], 7, 1337, n_pre=21, n_post=168, n_resp=128)
+    imgs, ids, tgts = i0 + i7, d0 + d7, t0_ + t7
+    l8, a8, g8 = _step(fx, imgs, ids, tgts, img_id, pad_id)
+    l8b, _, g8b = _step(fx, imgs, ids, tgts, img_id, pad_id)
+    assert torch.equal(l8, l8b) and all(torch.equal(g8[k], g8b[k]) for k in g8)      # reproducible at the benched M
+    n = int(a8["num_tokens"])
+    assert n == 8 * 128
+    acc = {k: torch.zeros_like(v, dtype=torch.float32) for k, v in g8.items()}
+    ls, nsum = 0.0, 0
+    for i in range(8):
+        li, ai, gi = _step(fx, imgs[i:i + 1], ids[i:i + 1], tgts[i:i + 1], img_id, pad_id)
+        ni = int(ai["num_tokens"])
+        nsum += ni
+        ls += float(ai["loss_sum"].float())
+        for k in acc:
+            acc[k] += gi[k].float() * (ni / n)
+    assert nsum == n
+    assert abs(float(a8["loss_sum"].float()) - ls) <= 3e-4 * abs(ls), (float(a8["loss_sum"].float()), ls)
+    scale = max(v.norm().item() / v.numel() ** 0.5 for v in acc.values())
+    rows = []
+    for k, gv in g8.items():
+        err = ((gv.float() - acc[k]).norm() / max(acc[k].norm().item(), 1e-3 * scale * gv.numel() ** 0.5)).item()
+        rows.append((err, k))
+    rows.sort(reverse=True)
+    print("B = 8 vs the token-weighted sum of eight B = 1 steps: worst gradients", rows[:4],
+          "median", rows[len(rows) // 2][0])
+    assert rows[0][0] <= tol, rows[:4]
+
+
+def test_c3_batch8_equals_token_weighted_sum_of_eight_singles(c3c):
+    _batch8_equals_eight_singles(c3c, 3e-2)
+
+
+def test_c4_batch8_equals_token_weighted_sum_of_eight_singles(c4c):
+    _batch8_equals_eight_singles(c4c, 3e-2)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -126,6 +126,61 @@ def test_kv_cache_decode_matches_full_recompute(native, monkeypatch):
         assert maxrel(lg, ref[:, pos]) <= 2e-2, t
 
 
+def test_kv_cache_decode_at_the_70b_shard_shape():
+    """BASELINE configs[4] at the shape ONE rank of the 8-way split holds (d = 8192, 8 q heads / 1 kv head x 128,
+    f = 28672 / 8 = 3584, V = 128256; 2 layers): prefill + 4 cached single-token steps through the native decode
+    drivers (GEMV with fused norm / SwiGLU operands, split-cache attention with one kv head) == the causal
+    training-path forward over the whole grown sequence, and == the fp32 oracle on the same weights.  The collectives
+    of the split are identities on one rank (TPContext()): the per-rank arithmetic is what is checked."""
+    from zero_amd.configs.config_base import LLAMA_SHAPES
+    from zero_amd.inference import decode
+    from zero_amd.inference.decode import KVCache, forward_cached
+    from zero_amd.models.llama import LlamaConfig, LlamaForCausalLM
+    assert decode.USE_NATIVE_DECODE and decode.USE_SPLIT_ATTENTION
+    sh = dict(LLAMA_SHAPES[("3.1", "70")])
+    sh.pop("translators_range")
+    factor = sh.pop("rope_factor")
+    W, L = 8, 2
+    lcfg = LlamaConfig(**{**sh, "num_attention_heads": sh["num_attention_heads"] // W,
+                          "num_key_value_heads": sh["num_key_value_heads"] // W,
+                          "intermediate_size": sh["intermediate_size"] // W, "num_hidden_layers": L})
+    lcfg.rope_scaling = dict(rope_type="llama3", factor=factor, low_freq_factor=1.0, high_freq_factor=4.0,
+                             original_max_position_embeddings=8192)
+    assert (lcfg.hidden_size, lcfg.num_attention_heads, lcfg.num_key_value_heads, lcfg.intermediate_size) == (8192, 8, 1, 3584)
+    torch.manual_seed(70)
+    dec = LlamaForCausalLM(lcfg, device=DEV)
+    with torch.no_grad():
+        for n, p in dec.named_parameters():
+            if "norm" in n:
+                p.copy_(1.0 + 0.1 * torch.randn_like(p.float()))
+            elif "o_proj" in n or "down_proj" in n:
+                p.normal_(0.0, 0.02 / (2 * L) ** 0.5)
+            else:
+                p.normal_(0.0, 0.02)
+    dec.eval()
+    odec = zo.DecoderCfg(hidden=lcfg.hidden_size, heads=lcfg.num_attention_heads, kv_heads=lcfg.num_key_value_heads,
+                         head_dim=lcfg.head_dim, intermediate=lcfg.intermediate_size, layers=L, vocab=lcfg.vocab_size,
+                         rope_factor=factor, tie=lcfg.tie_word_embeddings)
+    params = {"decoder." + k: v.detach().float().cpu() for k, v in dec.state_dict().items()}
+    g = torch.Generator(device="cpu").manual_seed(7)
+    B, S0, steps = 1, 203, 4                          # the cache crosses a 64-key chunk boundary at step 2... 3 chunks + 1
+    xs = torch.randn(B, S0 + steps, lcfg.hidden_size, generator=g).to(torch.bfloat16)
+    cache = KVCache(L, B, S0 + steps, lcfg.num_key_value_heads * lcfg.head_dim, DEV)
+    got = [forward_cached(dec, xs[:, :S0].to(DEV), cache)[:, 0]]
+    for t in range(steps):
+        got.append(forward_cached(dec, xs[:, S0 + t:S0 + t + 1].to(DEV), cache)[:, 0])
+    assert cache.length == S0 + steps and getattr(cache, "_plan", None) is not None      # the native drivers ran
+    with torch.no_grad():
+        full = dec(inputs_embeds=xs.to(DEV), use_cache=False)["logits"]
+    rows = [S0 - 1 + t for t in range(steps + 1)]
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+    ref = zo.llama_forward(params, xs.float(), odec)[:, rows]
+    for t, lg in enumerate(got):
+        assert maxrel(lg, full[:, rows[t]]) <= 1e-2, t
+        assert maxrel(lg, ref[:, t]) <= 2e-2, t
+        assert torch.equal(lg.float().argmax(-1).cpu(), ref[:, t].argmax(-1)) or maxrel(lg, ref[:, t]) <= 5e-3
+
+
 def test_graft_generate_matches_golden(golden_dir):
     from zero_amd.inference.vlm_infer import graft_generate, graft_inputs
     spec = GOLDEN_CONFIGS["graft"]
