@@ -66,6 +66,9 @@ def parse():
                     help="training stage of ref:configs/zero/train_llama.py (pretrain = adapter + translator layer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--n-resp", type=int, default=128,
+                    help="labelled (response) tokens per sample, <= 168: the default 128 mimics response-only loss "
+                         "(SURVEY.md §8d); 168 labels every text token after the image (label-dense variant)")
     ap.add_argument("--gemm-shapes", action="store_true", help="per-shape GEMM table on stderr")
     ap.add_argument("--gemm-gap", default="", metavar="FILE",
                     help="after the instrumented steps, replay every distinct GEMM call of the step in isolation "
@@ -292,7 +295,7 @@ def main():
 
     # ---- synthetic data: seeded per rank
     g = torch.Generator(device="cpu").manual_seed(1337 + rank)
-    n_pre, n_post, n_resp = 21, 168, 128
+    n_pre, n_post, n_resp = 21, 168, min(args.n_resp, 168)
     T = (img_size // 14) ** 2 + 1
     imgs_cpu, ids, tgts, img_id, pad_id = synth_batch(img_size, 128256, B, 1337 + rank, n_pre=n_pre, n_post=n_post,
                                                       n_resp=n_resp)

@@ -703,31 +703,56 @@ __device__ __forceinline__ void store_tile_p(const GemmArgs& g, f32x4 (&acc)[TM]
       for (int e = 0; e < 4; ++e) { bias[jj][2 * e] = lo_bf(b[e]); bias[jj][2 * e + 1] = hi_bf(b[e]); }
     }
   }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  // ZK_EPI_SWIGLU_BWD reads the saved gate|up values of every output element (as many bytes as it writes).  Loaded
+  // inside the pass that uses them, each of the TM * NJ passes stalled for one trip to memory (the matrix pipes idle
+  // meanwhile: 1.02 PF against the plain epilogue's 1.27-1.4); the loads of pass p + AUXD are now requested in pass p,
+  // AUXD passes (2 AUXD 16-byte registers per lane) ahead, so only the first trip of a tile is exposed.
+  constexpr int AUXD = 4, NPASS = TM * NJ;
+  const bool swiglu_bwd = EPI == 2 && epi == ZK_EPI_SWIGLU_BWD;
+  u32x4 gqb[EPI == 2 ? AUXD : 1], uqb[EPI == 2 ? AUXD : 1];
+  auto aux_load = [&](auto p_c) __attribute__((always_inline)) {
+    constexpr int P = decltype(p_c)::value;
+    if constexpr (EPI == 2 && P < NPASS) {
+      const int m = mw + (P / NJ) * 16 + rr, n = nw + (P % NJ) * 32 + rq * 8;
+      const int col = ((n >> 5) << 6) + (n & 31);
+      if (swiglu_bwd && m < g.M && n < g.N) {
+        gqb[P % AUXD] = *reinterpret_cast<const u32x4*>(g.aux_in + (size_t)m * g.ldaux + col);
+        uqb[P % AUXD] = *reinterpret_cast<const u32x4*>(g.aux_in + (size_t)m * g.ldaux + col + 32);
+      }
+    }
+  };
+  if constexpr (EPI == 2) static_for<AUXD>([&](auto p_c) { aux_load(p_c); });
+  static_assert(WAITN + 2 * AUXD <= 63, "vmcnt field");
+  static_for<TM>([&](auto i_c) {
+    constexpr int i = decltype(i_c)::value;
     const int m = mw + i * 16 + rr;
     float gate[8];
-#pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
+    static_for<NJ>([&](auto jj_c) {
+      constexpr int jj = decltype(jj_c)::value;
       *reinterpret_cast<f32x4*>(wp0) = acc[i][2 * jj];
       *reinterpret_cast<f32x4*>(wp1) = acc[i][2 * jj + 1];
       const f32x4 lo = *reinterpret_cast<const f32x4*>(rp0);
       const f32x4 hi = *reinterpret_cast<const f32x4*>(rp1);
       // the next tile's second K-tile (issued before this point) has landed once at most WAITN DMA
-      // instructions are left: wait here, before the first store enters the (in-order) vmcnt queue
-      if (i == 0 && jj == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+      // instructions are left (not counting the gate|up requests issued above, which are younger): wait here,
+      // before the first store enters the (in-order) vmcnt queue
+      if (i == 0 && jj == 0) {
+        if (swiglu_bwd) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN + 2 * AUXD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+      }
       if (EPI == 3) {
         if (lo[0] + hi[3] == 123.456f) g.C[0] = f2bf(lo[1]);
-        continue;
+        return;
       }
       const int n = nw + jj * 32 + rq * 8;
       const bool ok = m < g.M && n < g.N;
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       if (EPI == 2 && epi == ZK_EPI_SWIGLU_BWD) {
-        if (!ok) continue;
+        constexpr int P = i * NJ + jj;
+        const u32x4 gq = gqb[EPI == 2 ? P % AUXD : 0], uq = uqb[EPI == 2 ? P % AUXD : 0];
+        aux_load(std::integral_constant<int, P + AUXD>{});       // (its registers are free again: gq / uq are copies)
+        if (!ok) return;
         const int col = ((n >> 5) << 6) + (n & 31);
-        const u32x4 gq = *reinterpret_cast<const u32x4*>(g.aux_in + (size_t)m * g.ldaux + col);
-        const u32x4 uq = *reinterpret_cast<const u32x4*>(g.aux_in + (size_t)m * g.ldaux + col + 32);
         u32x4 og, ou;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -746,7 +771,7 @@ __device__ __forceinline__ void store_tile_p(const GemmArgs& g, f32x4 (&acc)[TM]
         }
         *reinterpret_cast<u32x4*>(g.C + (size_t)m * g.ldc + col) = og;
         *reinterpret_cast<u32x4*>(g.C + (size_t)m * g.ldc + col + 32) = ou;
-        continue;
+        return;
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha + bias[jj][e];
@@ -770,7 +795,7 @@ __device__ __forceinline__ void store_tile_p(const GemmArgs& g, f32x4 (&acc)[TM]
           }
         }
       }
-      if (!ok) continue;
+      if (!ok) return;
       if ((EPI < 2 || EPI == 4) && g.residual) {
         // x = residual + bf16(f(x)) : the branch output is rounded before the add
         const u32x4 r = *reinterpret_cast<const u32x4*>(g.residual + (size_t)m * g.ldr + n);
@@ -809,8 +834,8 @@ __device__ __forceinline__ void store_tile_p(const GemmArgs& g, f32x4 (&acc)[TM]
           *reinterpret_cast<u32x4*>(g.aux_out + (size_t)m * g.ldaux + (nw >> 1) + rq * 8) = o4;
         }
       }
-    }
-  }
+    });
+  });
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int RS, int NSLOT, bool LEAN, int EPI>

@@ -151,6 +151,8 @@ class FlatGradReducer:
             key = (t.untyped_storage().data_ptr(), t.storage_offset(), t.numel())
             if id(t) in mine or t.numel() == 0 or key in seen:       # tied weights: once
                 continue
+            if t.device != self.flat_param.device:                   # a host-side table: not this backend's to move
+                continue
             seen.add(key)
             frozen.append((n, t))
         if mode == "broadcast":
