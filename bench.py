@@ -121,15 +121,17 @@ def plan_name(plan: int) -> str:
 
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes over this same
-    command (profiles/r02_pmc_summary.json, written by tools/pmc_bench.sh + tools/pmc_summary.py:
+    command (profiles/r03_pmc_summary.json, written by tools/pmc_bench.sh + tools/pmc_summary.py:
     FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None if no summary is present."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-    try:
-        with open(path) as f:
-            ent = json.load(f)["kernels"].get(kernel)
-        return ent and ent["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        return None
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                ent = json.load(f)["kernels"].get(kernel)
+            if ent:
+                return ent["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def gemm_gap_table(lib, calls, shp, path, device):

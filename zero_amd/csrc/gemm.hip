@@ -1096,6 +1096,7 @@ struct Plan {
   int phase_delay = -1;  // persistent kernel start stagger, 10 ns ticks per phase step (-1 = built-in policy)
 };
 int g_num_cu[16] = {0};
+thread_local bool g_in_row_split = false;   // the two halves of a row-split product are not split again
 thread_local int g_last_plan = -1;   // kernel variant of this thread's last zk_gemm_bf16 call (zk_gemm_last_plan)
 
 int num_cus() {
@@ -1156,7 +1157,8 @@ bool pring_fits(int64_t M, int64_t N, int64_t lda, int64_t ldb, int epilogue) {
 }
 
 // Tile choice: time ~ rounds(tiles / concurrent blocks) x tile area / relative efficiency.
-int choose_tile(int64_t M, int64_t N, int64_t K, int transA, int transB, bool need_tn4, const Plan& P) {
+int choose_tile(int64_t M, int64_t N, int64_t K, int transA, int transB, bool need_tn4, const Plan& P,
+                double* cost_out = nullptr) {
   const bool nt_ring = !transA && !transB && P.ring;
   if (P.tile >= 0) {
     if (P.tile == 3 && (transB || need_tn4)) return 0;
@@ -1189,7 +1191,47 @@ int choose_tile(int64_t M, int64_t N, int64_t K, int transA, int transB, bool ne
     double cost = rounds * slots[c] * bm[c] * bn[c] / eff[c];
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
+  if (cost_out) *cost_out = best_cost;
   return best;
+}
+
+// Row split.  A product whose tiling leaves a nearly empty last round (C2's fc2: 580 tiles of 256x256 on 256 CUs =
+// 2.27 rounds, paid as 3) is cut into a part of whole rounds and a remainder that is dispatched as a product of
+// its own (for which the cost model picks its own tile, usually the small two-stage tiles that fill the chip with
+// few rows).  Both run on the caller's stream, one after the other.  Estimated times in microseconds from the cost
+// model's unit (tile area x rounds x slots / efficiency) at K: cost * 2K flops over ~1075 TFLOP/s at efficiency 1.0,
+// plus a launch / ramp / tail allowance per launch; the split is taken when it saves 7 % or more.
+// Returns the rows of the first part (a multiple of its tile height), 0 for "do not split".
+int64_t row_split(int64_t M, int64_t N, int64_t K, int transB, bool need_tn4, const Plan& P) {
+  if (M < 2048 || !P.ring || !P.pring || K % BK != 0 || K < 4 * BK) return 0;
+  const double us_per_cost = 2.0 * (double)K / 1.075e9, launch_us = 7.0;
+  double c0;
+  choose_tile(M, N, K, 0, transB, need_tn4, P, &c0);
+  const double t0 = c0 * us_per_cost + launch_us;
+  const int bm[3] = {256, 384, 192}, bn[3] = {256, 192, 256};
+  const double kf = K <= 2048 ? 0.0 : (K >= 4096 ? 1.0 : (double)(K - 2048) / 2048.0);
+  const double eff[3] = {1.3 + 0.05 * kf, 1.3 + 0.05 * kf, (1.3 + 0.05 * kf) * 0.94};
+  int64_t best_m1 = 0;
+  double best_t = t0 * 0.93;
+  for (int c = 0; c < 3; ++c) {
+    if (transB) break;                                   // the persistent ring runs NT products only
+    if (need_tn4 && c == 1) continue;
+    if (c == 2 && !P.lean && (N % 256 != 0)) continue;
+    const int64_t tn = (N + bn[c] - 1) / bn[c];
+    const int64_t rounds = ((M / bm[c]) * tn) / 256;     // whole rounds available
+    for (int64_t r = rounds; r >= 1 && r + 1 >= rounds; --r) {
+      const int64_t m1 = (r * 256 / tn) * bm[c];
+      if (m1 <= 0 || m1 >= M || M - m1 < 64) continue;
+      const double used = (double)((m1 / bm[c]) * tn) / (double)(r * 256);
+      if (used < 0.93) continue;                         // the "whole" rounds must be nearly full
+      const double t1 = (double)r * 256.0 * bm[c] * bn[c] / eff[c] * us_per_cost + launch_us;
+      double c2;
+      choose_tile(M - m1, N, K, 0, transB, need_tn4, P, &c2);
+      const double t = t1 + c2 * us_per_cost + launch_us;
+      if (t < best_t) { best_t = t; best_m1 = m1; }
+    }
+  }
+  return best_m1;
 }
 }  // namespace
 
@@ -1260,6 +1302,32 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
   g.phase_delay = 0;
   g.splits = 1; g.kchunk = (int)((K + BK - 1) / BK * BK); g.slab = nullptr;
   // split-K for small outputs with a long contraction (wgrad, lm_head dgrad): fill the 256 CUs
+  // ---- row split (built-in plan only): whole rounds on the persistent ring + the remainder as its own product
+#ifndef ZK_NO_ROW_SPLIT
+  if (!plan && !transA && !g_in_row_split) {
+    const bool plain_sk = epilogue == ZK_EPI_NONE && !bias && !residual && !aux_out && workspace &&
+                          ((M + 127) / 128) * ((N + 127) / 128) <= 1024 && K >= 1024;     // split-K territory below
+    const int64_t m1 = plain_sk ? 0 : row_split(M, N, K, transB, epilogue == ZK_EPI_SWIGLU, P);
+    if (m1 > 0) {
+      const int64_t ld_aux_out = epilogue == ZK_EPI_SWIGLU ? ldaux : ldc;    // (the GELU pre-activation copy has C's stride)
+      auto at = [](const void* p, int64_t elems) -> const void* {
+        return p ? static_cast<const void*>(static_cast<const bf16_t*>(p) + elems) : nullptr;
+      };
+      g_in_row_split = true;
+      int rc = zk_gemm_bf16_plan(A, B, C, m1, N, K, lda, ldb, ldc, transA, transB, epilogue, bias, residual, ldr, aux_out,
+                                 aux_in, ldaux, alpha, alpha_dev, accumulate, workspace, workspace_bytes, nullptr, stream);
+      const int main_plan = g_last_plan;
+      if (rc == ZK_OK)
+        rc = zk_gemm_bf16_plan(at(A, m1 * lda), B, const_cast<void*>(at(C, m1 * ldc)), M - m1, N, K, lda, ldb, ldc, transA,
+                               transB, epilogue, bias, at(residual, m1 * ldr), ldr,
+                               const_cast<void*>(at(aux_out, m1 * ld_aux_out)), at(aux_in, m1 * ldaux), ldaux, alpha,
+                               alpha_dev, accumulate, workspace, workspace_bytes, nullptr, stream);
+      g_in_row_split = false;
+      g_last_plan = main_plan;           // the measurement hook reports the kernel that did most of the work
+      return rc;
+    }
+  }
+#endif
   const bool plain = epilogue == ZK_EPI_NONE && !bias && !residual && !aux_out;
   if (plain && workspace && P.splits != 1) {
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
