@@ -70,8 +70,18 @@ struct KvRing {
   }
 };
 
+#ifdef ZK_ATTN_STAMPS
+// diagnostic build only (tools/attn_stamps.py): where a forward workgroup's time goes.  100 MHz wall-clock stamps of
+// wave 0 at entry / first tile landed / loop end / stores issued / stores drained, in a buffer nothing else reads.
+static __device__ unsigned long long g_stamps[8 * 16384];
+#define ZK_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ZK_STAMP(k) do { } while (0)
+#endif
+
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_fwd_kernel(AttnArgs a) {
+  ZK_STAMP(0);
   using C = Cfg<HD>;
   using R = KvRing<HD, 2>;
   constexpr int KV = R::KV;
@@ -114,6 +124,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_fwd_kernel(AttnArg
   for (int t = 0; t < nt; ++t) {
     R::wait_tiles(min(R::NST - 2, nt - 1 - t));
     __syncthreads();
+    if (t == 0) ZK_STAMP(1);
     if (t + R::NST - 1 < nt) R::issue(smem, rk, rv, t + R::NST - 1, a.S, a.ldk, a.ldv, kvh * HD, tid, wv);
     if (t >= nt_wave) continue;
     const unsigned char* kl = smem + (t % R::NST) * R::STAGE;
@@ -169,6 +180,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_fwd_kernel(AttnArg
       }
   }
 
+  ZK_STAMP(2);
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
   if (qi < a.S) {
@@ -184,7 +196,19 @@ __global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_fwd_kernel(AttnArg
       }
     if (h == 0 && a.lse) a.lse[((size_t)b * a.Hq + head) * a.S + qi] = m_run * LN2 + logf(l_tot);
   }
+  ZK_STAMP(3);
+#ifdef ZK_ATTN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ZK_STAMP(4);
+  if (threadIdx.x == 0 && blockIdx.x < 16384) { g_stamps[blockIdx.x * 8 + 5] = (unsigned long long)qblk; g_stamps[blockIdx.x * 8 + 6] = (unsigned long long)nt; }
+#endif
 }
+
+#ifdef ZK_ATTN_STAMPS
+extern "C" int zk_debug_read_stamps(void* host_dst, int nblocks) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), (size_t)nblocks * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -5;
+}
+#endif
 
 // =========================================================================================
 // backward: dQ  (per 128-query block, sweep over key tiles; same K/V ring as the forward)
