@@ -184,7 +184,10 @@ def _golden_parity(fx, gold):
     for k, v in rep.items():
         print(k, v)
     for e_f, fl_f, e_m, fl_m, nrm, n in rows:
-        assert e_f <= max(5e-2, 0.5 * fl_f), ("frobenius", n, e_f, fl_f)
+        # 6e-2 = the absolute cap of the strict (conditioned-init) fixtures below.  The worst of ~150 tensors moves by
+        # +-5 % between builds whose arithmetic differs by one fp32 ulp (4.95e-2 -> 5.16e-2 when the sigmoid's IEEE
+        # division became the hardware reciprocal): a cap within 1 % of one measurement tested the noise, not the path
+        assert e_f <= max(6e-2, 0.5 * fl_f), ("frobenius", n, e_f, fl_f)
         assert e_f <= max(fl_f, 1.5e-2), ("further from fp32 than transformers' own bf16 run", n, e_f, fl_f)
         assert e_m <= max(8e-2, 0.5 * fl_m), ("max-rel", n, e_m, fl_m)
         assert nrm <= 3e-2, ("gradient norm", n, nrm)

@@ -223,6 +223,86 @@ def test_gemm_persistent_ring_192x256(M, N, K):
         ops.set_gemm_tile(-1)
 
 
+@pytest.mark.parametrize("tile", [2, 4, 5], ids=["t256", "t384x192", "t192x256"])
+def test_gemm_ring_epilogue_stays_inside_its_operands(tile):
+    """The ring's epilogue reaches C / residual / the pre-activation copy through buffer descriptors that end at row M,
+    with masked columns sent out of range: an output that is a strided window of a larger canary buffer (ragged M and
+    N, row stride > N) must leave every element outside the window untouched, and equal the one-tile-per-workgroup
+    kernel inside it."""
+    M, N, K, LD, PAD = 4600, 4104, 320, 4104 + 72, 16
+    a, b = rnd(M, K, seed=151), rnd(N, K, seed=152, scale=0.5)
+    bias, res_full = rnd(N, seed=153), rnd(M + 2 * PAD, LD, seed=154)
+    res = res_full[PAD:PAD + M, 8:8 + N]
+
+    def window():
+        buf = torch.full((M + 2 * PAD, LD), 7.0, dtype=torch.bfloat16, device=DEV)
+        return buf, buf[PAD:PAD + M, 8:8 + N]
+
+    def untouched(buf):
+        probe = buf.clone()
+        probe[PAD:PAD + M, 8:8 + N] = 7.0
+        return bool((probe == 7.0).all())
+
+    try:
+        ops.set_gemm_tile(tile)
+        got = {}
+        for pr in (51, 50):
+            ops.set_gemm_tile(pr)
+            outs = []
+            for kw in (dict(), dict(bias=bias, residual=res), dict(bias=bias, epilogue=ops.EPI_QUICK_GELU, aux=True),
+                       dict(epilogue=ops.EPI_MUL_DGELU_ERF, aux_in=res, alpha=0.5)):
+                kw = dict(kw)
+                buf, win = window()
+                abuf = None
+                if kw.pop("aux", False):
+                    abuf, awin = window()
+                    kw["aux_out"] = awin
+                ops.gemm(a, b, out=win, **kw)
+                if pr == 51:
+                    assert ops.lib.zk_gemm_last_plan() // 1000 == 3, "persistent ring expected"
+                assert untouched(buf) and (abuf is None or untouched(abuf))
+                outs.append(win.clone())
+                if abuf is not None:
+                    outs.append(awin.clone())
+            got[pr] = outs
+        for x, y in zip(got[51], got[50]):
+            assert torch.equal(x, y)
+        assert relerr(got[51][0], a.float() @ b.float().t()) < 6e-3
+    finally:
+        ops.set_gemm_tile(51)
+        ops.set_gemm_tile(-1)
+
+
+def test_gemm_ring_swiglu_epilogues_stay_inside_their_operands():
+    """Same for the SwiGLU pair: ragged M, gate|up / h / d(gate|up) as windows of canary buffers."""
+    M, F, K, D = 4600, 2048, 320, 512
+    x, wi = rnd(M, K, seed=161), rnd(2 * F, K, seed=162, scale=0.2)
+    gu, h = ops.gemm_swiglu(x, wi)
+    assert ops.lib.zk_gemm_last_plan() // 1000 == 3
+    dy, wdt = rnd(M, D, seed=163), rnd(F, D, seed=164, scale=0.2)
+    dgu = ops.gemm_swiglu_bwd(dy, wdt, gu)
+    assert ops.lib.zk_gemm_last_plan() // 1000 == 3
+    PAD = 16
+    big_gu = torch.full((M + 2 * PAD, 2 * F + 64), 7.0, dtype=torch.bfloat16, device=DEV)
+    big_h = torch.full((M + 2 * PAD, F + 64), 7.0, dtype=torch.bfloat16, device=DEV)
+    big_d = torch.full((M + 2 * PAD, 2 * F + 64), 7.0, dtype=torch.bfloat16, device=DEV)
+    wgu, wh, wd = big_gu[PAD:PAD + M, :2 * F], big_h[PAD:PAD + M, :F], big_d[PAD:PAD + M, :2 * F]
+    ws = ops._workspace(x.device)
+    rc = ops._gemm_call(ops._p(x), ops._p(wi), ops._p(wgu), M, 2 * F, K, x.stride(0), wi.stride(0), wgu.stride(0), 0, 0,
+                        ops.EPI_SWIGLU, None, None, 0, ops._p(wh), None, wh.stride(0), 1.0, None, 0, ws.data_ptr(),
+                        ops.WORKSPACE_BYTES)
+    assert rc == 0 and ops.lib.zk_gemm_last_plan() // 1000 == 3
+    rc = ops._gemm_call(ops._p(dy), ops._p(wdt), ops._p(wd), M, F, D, dy.stride(0), wdt.stride(0), wd.stride(0), 0, 0,
+                        ops.EPI_SWIGLU_BWD, None, None, 0, None, ops._p(wgu), wgu.stride(0), 1.0, None, 0, ws.data_ptr(),
+                        ops.WORKSPACE_BYTES)
+    assert rc == 0 and ops.lib.zk_gemm_last_plan() // 1000 == 3
+    assert torch.equal(wgu, gu) and torch.equal(wh, h) and torch.equal(wd, dgu)
+    for big, win_cols in ((big_gu, 2 * F), (big_h, F), (big_d, 2 * F)):
+        probe = big.clone()
+        probe[PAD:PAD + M, :win_cols] = 7.0
+        assert bool((probe == 7.0).all())
+
+
 def test_gemm_persistent_ring_repeatable():
     """Same launch 20 times: a read that overtakes its DMA (or a slot refilled too early) shows up as
     run-to-run differences; also against the fp32 product at the decoder's gate|up shape."""

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* gu, bf16_
     unpack8(*reinterpret_cast<const u32x4*>(g + F), b);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float s = a[j] / (1.0f + __expf(-a[j]));
+      float s = silu_fast(a[j]);
       o[j] = bf2f(f2bf(s)) * b[j];            // tf:llama:175: act_fn(gate) is a bf16 tensor
     }
     *reinterpret_cast<u32x4*>(h + row * F + c * 8) = pack8(o);
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* dh, const
     unpack8(*reinterpret_cast<const u32x4*>(dh + row * F + c * 8), d);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float sg = 1.0f / (1.0f + __expf(-a[j]));
+      float sg = sigmoid_fast(a[j]);
       float silu = a[j] * sg;
       og[j] = d[j] * b[j] * sg * (1.0f + a[j] * (1.0f - sg));
       ou[j] = d[j] * silu;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* dy, const bf
     for (int j = 0; j < 8; ++j) {
       float g;
       if (kind == ZK_EPI_QUICK_GELU) {
-        float s = 1.0f / (1.0f + __expf(-1.702f * x[j]));
+        float s = sigmoid_fast(1.702f * x[j]);
         g = s * (1.0f + 1.702f * x[j] * (1.0f - s));
       } else {
         float cdf = 0.5f * (1.0f + erff(x[j] * 0.70710678118654752f));

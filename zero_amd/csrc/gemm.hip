@@ -57,10 +57,10 @@ struct GemmArgs {
 
 __device__ __forceinline__ int swz_t(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
 
-__device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float act_quick_gelu(float x) { return x * sigmoid_fast(1.702f * x); }
 __device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float dact_quick_gelu(float x) {
-  float s = 1.0f / (1.0f + __expf(-1.702f * x));
+  float s = sigmoid_fast(1.702f * x);
   return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 __device__ __forceinline__ float dact_gelu_erf(float x) {
@@ -211,7 +211,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, f32x4 (&acc)[TM][T
             const float gg = hh ? hi_bf(gq[e]) : lo_bf(gq[e]);
             const float uu = hh ? hi_bf(uq[e]) : lo_bf(uq[e]);
             const float d = bf2f(f2bf(v[2 * e + hh]));
-            const float sg = 1.0f / (1.0f + __expf(-gg));
+            const float sg = sigmoid_fast(gg);
             r0[hh] = d * uu * sg * (1.0f + gg * (1.0f - sg));
             r1[hh] = d * (gg * sg);
           }
@@ -277,7 +277,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, f32x4 (&acc)[TM][T
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
               const float gg = bf2f(f2bf(pr[2 * e + hh])), uu = bf2f(f2bf(pr[32 + 2 * e + hh]));
-              const float sl = gg / (1.0f + __expf(-gg));
+              const float sl = silu_fast(gg);
               r[hh] = bf2f(f2bf(sl)) * uu;      // tf:llama:175: act_fn(gate) is a bf16 tensor
             }
             o4[e] = pack2bf(r[0], r[1]);
@@ -675,71 +675,95 @@ __device__ __forceinline__ int patch_swz(int r) { return ((r >> 1) & 3) | ((r & 
 // Write side: lane (r = l & 15, g = l >> 4) owns C[r][4g..4g+3] of a 16x16 fragment; read side: lane
 // (row = l >> 2, q = l & 3) gets 8 consecutive columns of one row: a wave-instruction stores 16 rows
 // x 64 bytes.  Chunk c (16 bytes) of row r lives at chunk c ^ patch_swz(r): conflict-free both ways.
-// EPI selects the code that is compiled in: 0 = alpha / bias / residual / accumulate, 1 = the
-// quick-GELU pair (forward with pre-activation copy, backward multiply), 2 = the SwiGLU pair,
-// 3 = nothing (ablation).
+// EPI selects the code that is compiled in: 0 = alpha / bias; 6 = 0 + residual; 1 = the
+// quick-GELU pair (forward with pre-activation copy, backward multiply); 4 = the erf-GELU pair; 2 = SwiGLU forward;
+// 5 = SwiGLU backward; 3 = nothing (ablation).
+//
+// Every global access of the passes is a BUFFER instruction through a descriptor that ends at the operand's last row
+// (M * ld * 2 bytes; 0 bytes for an operand the call does not have): rows past M, masked columns (offset 2 GiB) and
+// absent operands are out of range for the hardware — loads return zeros, stores are dropped — so the TM * NJ passes
+// are ONE straight line of code without a single branch around a memory instruction.  That is what lets the operands
+// an epilogue READS (saved gate|up, residual, old C, saved pre-activation) be requested AUXD passes ahead: vmcnt
+// counts in order, and only in branch-free code can the compiler (and the hand-placed wait below) know how many
+// younger requests stand behind a load.  With the loads and stores in `if (row < M)` blocks, as they were through
+// round 2, every wait the compiler placed was vmcnt(0): each pass of the residual / SwiGLU-backward epilogues drained
+// the stores of the pass before it and the next tile's DMA (profiles/r03_gemm_epilogue_branchfree.txt).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* p, int rows, int ld) {
+  return make_rsrc(p, p ? (unsigned)rows * (unsigned)ld * 2u : 0u);
+}
+__device__ __forceinline__ u32x4 epi_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+}
+__device__ __forceinline__ void epi_store(__amdgpu_buffer_rsrc_t r, unsigned off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+}
+
 template <int TM, int TN, int WAITN, int EPI>
 __device__ __forceinline__ void store_tile_p(const GemmArgs& g, f32x4 (&acc)[TM][TN], int mw, int nw, int lane,
                                              unsigned char* patch) {
   static_assert(TN % 2 == 0, "two fragments per pass");
-  constexpr int NJ = TN / 2;
+  constexpr int NJ = TN / 2, NPASS = TM * NJ;
+  constexpr int NLD = EPI == 5 ? 2 : (EPI == 1 || EPI == 4 || EPI == 6) ? 1 : 0;       // register loads per pass
+  // request distance, in passes (4 VGPRs per operand and pass): the 384x192 tile holds 144 accumulators and the next
+  // tile's 72 fragment registers through the epilogue, which leaves room for 16
+  constexpr int AUXD = (TM * TN > 32 && NLD == 2) ? 2 : 4;
+  static_assert(WAITN + NLD * AUXD <= 63, "vmcnt field");
+  constexpr unsigned OOB = 0x80000000u;                  // past every descriptor (host: operands under 2 GiB)
   const int wr = lane & 15, wg = lane >> 4, rr = lane >> 2, rq = lane & 3;
   unsigned char* wp0 = patch + wr * 128 + ((wg ^ patch_swz(wr)) << 4);
   unsigned char* wp1 = patch + wr * 128 + (((4 + wg) ^ patch_swz(wr)) << 4);
   const unsigned char* rp0 = patch + rr * 128 + (((2 * rq) ^ patch_swz(rr)) << 4);
   const unsigned char* rp1 = patch + rr * 128 + (((2 * rq + 1) ^ patch_swz(rr)) << 4);
   const int epi = g.epilogue;
+  const bool fwd_act = epi == ZK_EPI_QUICK_GELU || epi == ZK_EPI_GELU_ERF;              // classes 1 / 4: forward member
   float alpha = g.alpha;
   if (g.alpha_dev) alpha *= *g.alpha_dev;
-  float bias[NJ][8];
+  u32x4 biasq[NJ];                          // kept packed (4 registers per 8 columns), unpacked where it is added
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bias[jj][e] = 0.f;
+    biasq[jj] = u32x4{0u, 0u, 0u, 0u};
     const int n = nw + jj * 32 + rq * 8;
-    if ((EPI < 2 || EPI == 4) && g.bias && n < g.N) {
-      const u32x4 b = *reinterpret_cast<const u32x4*>(g.bias + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { bias[jj][2 * e] = lo_bf(b[e]); bias[jj][2 * e + 1] = hi_bf(b[e]); }
-    }
+    if ((EPI < 2 || EPI == 4 || EPI == 6) && g.bias && n < g.N) biasq[jj] = *reinterpret_cast<const u32x4*>(g.bias + n);
   }
-  // ZK_EPI_SWIGLU_BWD reads the saved gate|up values of every output element (as many bytes as it writes).  Loaded
-  // inside the pass that uses them, each of the TM * NJ passes stalled for one trip to memory (the matrix pipes idle
-  // meanwhile: 1.02 PF against the plain epilogue's 1.27-1.4); the loads of pass p + AUXD are now requested in pass p,
-  // AUXD passes (2 AUXD 16-byte registers per lane) ahead, so only the first trip of a tile is exposed.
-  constexpr int AUXD = 4, NPASS = TM * NJ;
-  const bool swiglu_bwd = EPI == 2 && epi == ZK_EPI_SWIGLU_BWD;
-  u32x4 gqb[EPI == 2 ? AUXD : 1], uqb[EPI == 2 ? AUXD : 1];
-  auto aux_load = [&](auto p_c) __attribute__((always_inline)) {
+  const __amdgpu_buffer_rsrc_t rC = epi_rsrc(g.C, g.M, g.ldc);
+  // the operands of the two prefetched loads (A, B) and of the second store (X), by class
+  const __amdgpu_buffer_rsrc_t rA = EPI == 5   ? epi_rsrc(g.aux_in, g.M, g.ldaux)
+                                    : EPI == 6 ? epi_rsrc(g.residual, g.M, g.ldr)
+                                               : epi_rsrc(fwd_act ? nullptr : g.aux_in, g.M, g.ldaux);
+  const __amdgpu_buffer_rsrc_t rX = EPI == 2 ? epi_rsrc(g.aux_out, g.M, g.ldaux)
+                                             : epi_rsrc(fwd_act ? g.aux_out : nullptr, g.M, g.ldc);
+  const int ld_a = EPI == 6 ? g.ldr : g.ldaux;
+  u32x4 pa[NLD >= 1 ? AUXD : 1], pb[NLD >= 2 ? AUXD : 1];
+  auto prefetch = [&](auto p_c) __attribute__((always_inline)) {
     constexpr int P = decltype(p_c)::value;
-    if constexpr (EPI == 2 && P < NPASS) {
+    if constexpr (NLD > 0 && P < NPASS) {
       const int m = mw + (P / NJ) * 16 + rr, n = nw + (P % NJ) * 32 + rq * 8;
-      const int col = ((n >> 5) << 6) + (n & 31);
-      if (swiglu_bwd && m < g.M && n < g.N) {
-        gqb[P % AUXD] = *reinterpret_cast<const u32x4*>(g.aux_in + (size_t)m * g.ldaux + col);
-        uqb[P % AUXD] = *reinterpret_cast<const u32x4*>(g.aux_in + (size_t)m * g.ldaux + col + 32);
+      const bool ok = m < g.M && n < g.N;
+      if constexpr (EPI == 5) {               // saved gate|up, interleaved in blocks of 32: [32 gate | 32 up]
+        const unsigned off = ((unsigned)m * (unsigned)g.ldaux + (unsigned)(((n >> 5) << 6) + (n & 31))) * 2u;
+        pa[P % AUXD] = epi_load(rA, ok ? off : OOB);
+        pb[P % AUXD] = epi_load(rA, ok ? off + 64u : OOB);
+      } else {
+        pa[P % AUXD] = epi_load(rA, ok ? ((unsigned)m * (unsigned)ld_a + (unsigned)n) * 2u : OOB);
       }
     }
   };
-  if constexpr (EPI == 2) static_for<AUXD>([&](auto p_c) { aux_load(p_c); });
-  static_assert(WAITN + 2 * AUXD <= 63, "vmcnt field");
+  static_for<AUXD>([&](auto p_c) { prefetch(p_c); });
   static_for<TM>([&](auto i_c) {
     constexpr int i = decltype(i_c)::value;
     const int m = mw + i * 16 + rr;
     float gate[8];
     static_for<NJ>([&](auto jj_c) {
       constexpr int jj = decltype(jj_c)::value;
+      constexpr int P = i * NJ + jj;
       *reinterpret_cast<f32x4*>(wp0) = acc[i][2 * jj];
       *reinterpret_cast<f32x4*>(wp1) = acc[i][2 * jj + 1];
       const f32x4 lo = *reinterpret_cast<const f32x4*>(rp0);
       const f32x4 hi = *reinterpret_cast<const f32x4*>(rp1);
-      // the next tile's second K-tile (issued before this point) has landed once at most WAITN DMA
-      // instructions are left (not counting the gate|up requests issued above, which are younger): wait here,
-      // before the first store enters the (in-order) vmcnt queue
-      if (i == 0 && jj == 0) {
-        if (swiglu_bwd) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN + 2 * AUXD) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
-      }
+      // the next tile's second K-tile (issued before this point) has landed once at most WAITN DMA instructions are
+      // left, not counting the NLD * AUXD requests issued above, which are younger: wait here, before the first
+      // store enters the (in-order) vmcnt queue
+      if (P == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN + NLD * AUXD) : "memory");
       if (EPI == 3) {
         if (lo[0] + hi[3] == 123.456f) g.C[0] = f2bf(lo[1]);
         return;
@@ -747,12 +771,9 @@ __device__ __forceinline__ void store_tile_p(const GemmArgs& g, f32x4 (&acc)[TM]
       const int n = nw + jj * 32 + rq * 8;
       const bool ok = m < g.M && n < g.N;
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      if (EPI == 2 && epi == ZK_EPI_SWIGLU_BWD) {
-        constexpr int P = i * NJ + jj;
-        const u32x4 gq = gqb[EPI == 2 ? P % AUXD : 0], uq = uqb[EPI == 2 ? P % AUXD : 0];
-        aux_load(std::integral_constant<int, P + AUXD>{});       // (its registers are free again: gq / uq are copies)
-        if (!ok) return;
-        const int col = ((n >> 5) << 6) + (n & 31);
+      if constexpr (EPI == 5) {
+        const u32x4 gq = pa[P % AUXD], uq = pb[P % AUXD];
+        prefetch(std::integral_constant<int, P + AUXD>{});
         u32x4 og, ou;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -762,32 +783,35 @@ __device__ __forceinline__ void store_tile_p(const GemmArgs& g, f32x4 (&acc)[TM]
             const float gg = hh ? hi_bf(gq[e]) : lo_bf(gq[e]);
             const float uu = hh ? hi_bf(uq[e]) : lo_bf(uq[e]);
             const float d = bf2f(f2bf(v[2 * e + hh]));
-            const float sg = 1.0f / (1.0f + __expf(-gg));
+            const float sg = sigmoid_fast(gg);
             r0[hh] = d * uu * sg * (1.0f + gg * (1.0f - sg));
             r1[hh] = d * (gg * sg);
           }
           og[e] = pack2bf(r0[0], r0[1]);
           ou[e] = pack2bf(r1[0], r1[1]);
         }
-        *reinterpret_cast<u32x4*>(g.C + (size_t)m * g.ldc + col) = og;
-        *reinterpret_cast<u32x4*>(g.C + (size_t)m * g.ldc + col + 32) = ou;
+        const unsigned off = ((unsigned)m * (unsigned)g.ldc + (unsigned)(((n >> 5) << 6) + (n & 31))) * 2u;
+        epi_store(rC, ok ? off : OOB, og);
+        epi_store(rC, ok ? off + 64u : OOB, ou);
         return;
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha + bias[jj][e];
-      if ((EPI == 1 || EPI == 4) && ok) {      // 1: the quick-GELU pair, 4: the erf-GELU pair (adapter)
-        if (epi == ZK_EPI_QUICK_GELU || epi == ZK_EPI_GELU_ERF) {
-          u32x4 pre;
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha + ((e & 1) ? hi_bf(biasq[jj][e >> 1]) : lo_bf(biasq[jj][e >> 1]));
+      const unsigned offc = ok ? ((unsigned)m * (unsigned)g.ldc + (unsigned)n) * 2u : OOB;
+      if constexpr (EPI == 1 || EPI == 4) {      // 1: the quick-GELU pair, 4: the erf-GELU pair (adapter)
+        const u32x4 h = pa[P % AUXD];
+        prefetch(std::integral_constant<int, P + AUXD>{});
+        u32x4 pre;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) pre[e] = pack2bf(v[2 * e], v[2 * e + 1]);
-          if (g.aux_out) *reinterpret_cast<u32x4*>(g.aux_out + (size_t)m * g.ldc + n) = pre;
+        for (int e = 0; e < 4; ++e) pre[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+        epi_store(rX, offc, pre);                // (forward with a pre-activation copy; dropped otherwise)
+        if (fwd_act) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             v[2 * e] = EPI == 1 ? act_quick_gelu(lo_bf(pre[e])) : act_gelu_erf(lo_bf(pre[e]));
             v[2 * e + 1] = EPI == 1 ? act_quick_gelu(hi_bf(pre[e])) : act_gelu_erf(hi_bf(pre[e]));
           }
         } else {
-          const u32x4 h = *reinterpret_cast<const u32x4*>(g.aux_in + (size_t)m * g.ldaux + n);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float x = (e & 1) ? hi_bf(h[e >> 1]) : lo_bf(h[e >> 1]);
@@ -795,23 +819,17 @@ __device__ __forceinline__ void store_tile_p(const GemmArgs& g, f32x4 (&acc)[TM]
           }
         }
       }
-      if (!ok) return;
-      if ((EPI < 2 || EPI == 4) && g.residual) {
+      if constexpr (EPI == 6) {
+        const u32x4 r = pa[P % AUXD];
+        prefetch(std::integral_constant<int, P + AUXD>{});
         // x = residual + bf16(f(x)) : the branch output is rounded before the add
-        const u32x4 r = *reinterpret_cast<const u32x4*>(g.residual + (size_t)m * g.ldr + n);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e])) + ((e & 1) ? hi_bf(r[e >> 1]) : lo_bf(r[e >> 1]));
-      }
-      bf16_t* cp = g.C + (size_t)m * g.ldc + n;
-      if ((EPI < 2 || EPI == 4) && g.accumulate) {
-        const u32x4 o = *reinterpret_cast<const u32x4*>(cp);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (e & 1) ? hi_bf(o[e >> 1]) : lo_bf(o[e >> 1]);
       }
       u32x4 out;
 #pragma unroll
       for (int e = 0; e < 4; ++e) out[e] = pack2bf(v[2 * e], v[2 * e + 1]);
-      if (EPI != 2 || g.C) *reinterpret_cast<u32x4*>(cp) = out;   // (null C: ZK_EPI_SWIGLU without the gate|up copy)
+      epi_store(rC, offc, out);                  // (null C: ZK_EPI_SWIGLU without the gate|up copy)
       if constexpr (TN == 4 && EPI == 2) {
         // ZK_EPI_SWIGLU: this wave's 64 columns are one interleave block [32 gate | 32 up]: jj = 0
         // delivered the lane's 8 gate features, jj = 1 the matching up features of the same row
@@ -826,12 +844,12 @@ __device__ __forceinline__ void store_tile_p(const GemmArgs& g, f32x4 (&acc)[TM]
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
               const float gg = gate[2 * e + hh], uu = hh ? hi_bf(out[e]) : lo_bf(out[e]);
-              const float sl = gg / (1.0f + __expf(-gg));
+              const float sl = silu_fast(gg);
               r[hh] = bf2f(f2bf(sl)) * uu;      // tf:llama:175: act_fn(gate) is a bf16 tensor
             }
             o4[e] = pack2bf(r[0], r[1]);
           }
-          *reinterpret_cast<u32x4*>(g.aux_out + (size_t)m * g.ldaux + (nw >> 1) + rq * 8) = o4;
+          epi_store(rX, ok ? ((unsigned)m * (unsigned)g.ldaux + (unsigned)((nw >> 1) + rq * 8)) * 2u : OOB, o4);
         }
       }
     });
@@ -1149,11 +1167,28 @@ int splitk_choice(int64_t tiles, int64_t M, int64_t N, int64_t K, bool transpose
 }
 
 // persistent ring: byte offsets from the matrix base are 32-bit, and the epilogue must be one of its classes
-bool pring_fits(int64_t M, int64_t N, int64_t lda, int64_t ldb, int epilogue) {
-  const bool cls = epilogue == ZK_EPI_NONE || epilogue == ZK_EPI_QUICK_GELU || epilogue == ZK_EPI_MUL_DQUICK_GELU ||
-                   epilogue == ZK_EPI_SWIGLU || epilogue == ZK_EPI_SWIGLU_BWD || epilogue == ZK_EPI_GELU_ERF ||
-                   epilogue == ZK_EPI_MUL_DGELU_ERF;
-  return cls && (M + 64) * lda * 2 < 0x7FFFFFF0LL && (N + 64) * ldb * 2 < 0x7FFFFFF0LL;
+// Epilogue class of the persistent ring for a call (store_tile_p), or -1 if none of them covers it
+int pring_class(int epilogue, bool has_residual, bool accumulate) {
+  if (accumulate) return -1;                 // (C += ... only occurs on transposed products, which the ring does not take)
+  if (epilogue == ZK_EPI_NONE) return has_residual ? 6 : 0;
+  if (has_residual) return -1;
+  if (epilogue == ZK_EPI_QUICK_GELU || epilogue == ZK_EPI_MUL_DQUICK_GELU) return 1;
+  if (epilogue == ZK_EPI_SWIGLU) return 2;
+  if (epilogue == ZK_EPI_SWIGLU_BWD) return 5;
+  if (epilogue == ZK_EPI_GELU_ERF || epilogue == ZK_EPI_MUL_DGELU_ERF) return 4;
+  return -1;
+}
+// The persistent ring addresses whole operands with 32-bit byte offsets: A / B through the DMA descriptors (64 rows of
+// slack for ragged tiles), every epilogue operand through a descriptor that ends at its last row
+bool pring_fits(int64_t M, int64_t N, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldaux, int epilogue,
+                bool has_residual, bool accumulate) {
+  const int64_t lim = 0x7FFFFFF0LL;
+  if (pring_class(epilogue, has_residual, accumulate) < 0) return false;
+  if ((M + 64) * lda * 2 >= lim || (N + 64) * ldb * 2 >= lim || M * ldc * 2 >= lim) return false;
+  if (has_residual && M * ldr * 2 >= lim) return false;
+  const bool uses_aux = epilogue == ZK_EPI_SWIGLU || epilogue == ZK_EPI_SWIGLU_BWD ||
+                        epilogue == ZK_EPI_MUL_DQUICK_GELU || epilogue == ZK_EPI_MUL_DGELU_ERF;
+  return !(uses_aux && M * ldaux * 2 >= lim);
 }
 
 // Tile choice: time ~ rounds(tiles / concurrent blocks) x tile area / relative efficiency.
@@ -1356,7 +1391,8 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
   // the 192x256 tile exists on the persistent ring only, which needs whole-matrix 32-bit byte offsets (operands
   // under 2 GiB) and one of its epilogue classes: anything else runs as the 256x256 tile, whose one-workgroup-per-
   // tile ring / two-stage kernels take every shape (a plain zk_gemm_bf16 call must not fail on a tile choice)
-  if (tile == 5 && !pring_fits(M, N, lda, ldb, epilogue)) tile = 2;
+  const bool ring_ok = pring_fits(M, N, lda, ldb, ldc, ldr, ldaux, epilogue, residual != nullptr, accumulate != 0);
+  if (tile == 5 && !ring_ok) tile = 2;
   g_last_plan = tile * 100;            // plain two-stage kernel unless a ring variant takes over below
   switch (tile) {
     case 3: launch_cfg<128, 96, 2, 2>(g, transA, transB, stream, P); break;
@@ -1371,13 +1407,8 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
         const bool lean = g.M % bm == 0 && g.N % bn == 0 && g.K % BK == 0 && P.lean;   // one-workgroup-per-tile ring
         const bool lean_p = g.K % BK == 0 && P.lean;   // persistent ring: ragged M / N fall out of the descriptors
         // persistent ring: needs >= 4 K-tiles per tile and whole-matrix 32-bit byte offsets
-        const int pclass = P.ring_mode == 3 ? 3
-                           : epilogue == ZK_EPI_NONE ? 0
-                           : (epilogue == ZK_EPI_QUICK_GELU || epilogue == ZK_EPI_MUL_DQUICK_GELU) ? 1
-                           : (epilogue == ZK_EPI_SWIGLU || epilogue == ZK_EPI_SWIGLU_BWD) ? 2
-                           : (epilogue == ZK_EPI_GELU_ERF || epilogue == ZK_EPI_MUL_DGELU_ERF) ? 4 : -1;
-        if (P.pring && pclass >= 0 && (g.K + BK - 1) / BK >= 4 && (M + 64) * lda * 2 < 0x7FFFFFF0LL &&
-            (N + 64) * ldb * 2 < 0x7FFFFFF0LL && (P.ring_mode == 0 || P.ring_mode == 3)) {
+        const int pclass = P.ring_mode == 3 ? 3 : pring_class(epilogue, residual != nullptr, accumulate != 0);
+        if (P.pring && pclass >= 0 && ring_ok && (g.K + BK - 1) / BK >= 4 && (P.ring_mode == 0 || P.ring_mode == 3)) {
           const int ncu = num_cus();
           const int ntl = gr.tiles_m * gr.tiles_n;
           const dim3 pg(ntl < ncu ? ntl : ncu);
@@ -1391,7 +1422,14 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
           // phases 3 us apart spreads every later tile boundary; measured (tools/bench_phase.py): fused
           // gate|up 589 -> 501 us, fused down-dgrad 316 -> 294, lm_head 710 -> 684, C2 fc1 437 -> 412;
           // with fewer than 3 tiles per workgroup the 9 us tail is not earned back.
-          gr.phase_delay = P.phase_delay >= 0 ? P.phase_delay : (ntl >= 3 * ncu ? 300 : 0);
+          // Round 3 (branch-free epilogues, tools/bench_phase.py again): the light epilogues (classes 0 / 6) keep 3 us;
+          // the heavy ones (activation pairs: twice the stores plus the vector work) want about 1 us per tile round,
+          // between 3 and 6 (fused gate|up, 6 rounds: 468 us at 3, 454 at 6; SwiGLU backward, 3 rounds: 269 at 3)
+          const int rounds = ntl / ncu;
+          const int heavy_us = rounds < 3 ? 3 : (rounds > 6 ? 6 : rounds);
+          gr.phase_delay = P.phase_delay >= 0 ? P.phase_delay
+                           : ntl < 3 * ncu     ? 0
+                           : (pclass == 0 || pclass == 6 || pclass == 3) ? 300 : heavy_us * 100;
 #define ZK_PRING(EPI_) \
   do { \
     if (tile == 5) hipLaunchKernelGGL((gemm_pring_kernel<192, 256, 2, 4, 64, 14, true, EPI_>), pg, dim3(512), 0, stream, gr); \
@@ -1404,6 +1442,8 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
           else if (pclass == 1) ZK_PRING(1);
           else if (pclass == 2) ZK_PRING(2);
           else if (pclass == 4) ZK_PRING(4);
+          else if (pclass == 5) ZK_PRING(5);
+          else if (pclass == 6) ZK_PRING(6);
           else ZK_PRING(3);
 #undef ZK_PRING
           break;

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* x, const bf16_t
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float g0 = lo_bf(xv[e]), g1 = hi_bf(xv[e]);
-              const float s0 = bf2f(f2bf(g0 / (1.0f + __expf(-g0)))), s1 = bf2f(f2bf(g1 / (1.0f + __expf(-g1))));
+              const float s0 = bf2f(f2bf(silu_fast(g0))), s1 = bf2f(f2bf(silu_fast(g1)));
               xv[e] = pack2bf(s0 * lo_bf(uv[e]), s1 * hi_bf(uv[e]));
             }
           }
