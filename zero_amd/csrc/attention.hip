@@ -56,10 +56,10 @@ struct KvRing {
       const int row = sidx / (HD / 8), ch = (sidx % (HD / 8)) ^ swz_key<HD>(row);
       const bool ok = kn + row < S;
       unsigned char* dst = st + (wv * 64 + 256 * i) * 16;   // wave-uniform; the hardware adds lane * 16
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)dst, 16,
-                                               ok ? (unsigned)(((kn + row) * ldk + col0 + ch * 8) * 2) : 0xFFFFFFF0u, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(dst + TILE), 16,
-                                               ok ? (unsigned)(((kn + row) * ldv + col0 + ch * 8) * 2) : 0xFFFFFFF0u, 0, 0, 0);
+      lds_dma<16>(rk, dst,
+                                               ok ? (unsigned)(((kn + row) * ldk + col0 + ch * 8) * 2) : 0xFFFFFFF0u);
+      lds_dma<16>(rv, (dst + TILE),
+                                               ok ? (unsigned)(((kn + row) * ldv + col0 + ch * 8) * 2) : 0xFFFFFFF0u);
     }
   }
   // at most n tiles may stay in flight (n <= NST - 2)
@@ -120,6 +120,10 @@ __global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_fwd_kernel(AttnArg
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;   // running max in the scaled log2 domain
+  // Q has arrived before the loop starts: a first use INSIDE the loop makes the compiler wait there with vmcnt(0) on
+  // every iteration (it cannot count across the back edge), which would also drain the K/V DMA it does not know about
+#pragma unroll
+  for (int ds = 0; ds < C::DS; ++ds) asm volatile("" ::"v"(qf[ds]));
 
   for (int t = 0; t < nt; ++t) {
     R::wait_tiles(min(R::NST - 2, nt - 1 - t));
@@ -269,6 +273,10 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(Attn
   for (int d = 0; d < C::DB; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+  // (every register the prologue loaded is waited for here, not at its first use inside the loop: see attn_fwd_kernel)
+#pragma unroll
+  for (int ds = 0; ds < C::DS; ++ds) asm volatile("" ::"v"(qf[ds]), "v"(dof[ds]));
+  asm volatile("" ::"v"(lse2), "v"(dlt));
 
   for (int t = 0; t < nt; ++t) {
     R::wait_tiles(min(R::NST - 2, nt - 1 - t));
@@ -434,16 +442,16 @@ __global__ __launch_bounds__(256 * GW, 2) void attn_bwd_dkdv_kernel(AttnArgs a) 
       const int row = sidx / C::CPR, ch = (sidx % C::CPR) ^ swz_key<HD>(row);
       const bool ok = qb + row < a.S;
       unsigned char* dst = st + ((tid & ~63) + NT * i) * 16;   // wave-uniform; the hardware adds lane * 16
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)dst, 16,
-                                               ok ? (unsigned)(((qb + row) * a.ldq + hq * HD + ch * 8) * 2) : 0xFFFFFFF0u, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (__attribute__((address_space(3))) void*)(dst + TILE), 16,
-                                               ok ? (unsigned)(((qb + row) * a.ldo + hq * HD + ch * 8) * 2) : 0xFFFFFFF0u, 0, 0, 0);
+      lds_dma<16>(rq, dst,
+                                               ok ? (unsigned)(((qb + row) * a.ldq + hq * HD + ch * 8) * 2) : 0xFFFFFFF0u);
+      lds_dma<16>(rdo, (dst + TILE),
+                                               ok ? (unsigned)(((qb + row) * a.ldo + hq * HD + ch * 8) * 2) : 0xFFFFFFF0u);
     }
     // one dword per lane: wave 0 brings lse[qb..qb+63], wave 1 delta[...]; the others a zero fill
     // (every wave issues the same number of loads, so one counted vmcnt serves all)
     const bool sok = wv < 2 && qb + lane < a.S;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rstat, (__attribute__((address_space(3))) void*)(st + 2 * TILE + wv * 256), 4,
-                                             sok ? (unsigned)((hq * a.S + qb + lane) * 4) : 0xFFFFFFF0u, 0, 0, 0);
+    lds_dma<4>(rstat, (st + 2 * TILE + wv * 256),
+                                               sok ? (unsigned)((hq * a.S + qb + lane) * 4) : 0xFFFFFFF0u);
   };
   auto wait_tiles = [&](int n) {   // at most n tiles may stay in flight
     if (n >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
@@ -458,11 +466,14 @@ __global__ __launch_bounds__(256 * GW, 2) void attn_bwd_dkdv_kernel(AttnArgs a) 
       const int sidx = tid + NT * i;
       const int row = sidx / C::CPR, ch = (sidx % C::CPR) ^ swz_key<HD>(row);
       const bool ok = kblk * 128 + row < a.S;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(vl + ((tid & ~63) + NT * i) * 16), 16,
-                                               ok ? (unsigned)(((kblk * 128 + row) * a.ldv + kvh * HD + ch * 8) * 2) : 0xFFFFFFF0u, 0, 0, 0);
+      lds_dma<16>(rv, (vl + ((tid & ~63) + NT * i) * 16),
+                                               ok ? (unsigned)(((kblk * 128 + row) * a.ldv + kvh * HD + ch * 8) * 2) : 0xFFFFFFF0u);
     }
   }
   for (int it = 0; it < NST - 1 && it < niter; ++it) issue(it);
+  // (K fragments waited for here, not at their first use inside the loop: see attn_fwd_kernel)
+#pragma unroll
+  for (int ds = 0; ds < C::DS; ++ds) asm volatile("" ::"v"(kf[ds]));
 
   for (int it = 0; it < niter; ++it) {
     // tile `it` has landed (each wave waits for its own pieces, the barrier covers the others'),

@@ -40,8 +40,8 @@ __device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t r, unsigned char
     const int row = sidx / CPR, ch = (sidx % CPR) ^ swz_key<HD>(row);
     const bool ok = valid && row0 + row < S;
     unsigned char* dst = dst_tile + (wv * 64 + 256 * i) * 16;   // wave-uniform; the hardware adds lane * 16
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16,
-                                             ok ? (unsigned)(((row0 + row) * ld + col0 + ch * 8) * 2) : 0xFFFFFFF0u, 0, 0, 0);
+    lds_dma<16, true>(r, dst,
+                                               ok ? (unsigned)(((row0 + row) * ld + col0 + ch * 8) * 2) : 0xFFFFFFF0u);
   }
 }
 
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     unsigned char* dst = (isk ? kring : vring) + (tile % NST) * TILE + (wv * 64 + 256 * ii) * 16;
     const int ld = isk ? a.ldk : a.ldv;
     const unsigned off = (unsigned)(((tile * KV + row) * ld + kvh * HD + ch * 8) * 2);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(isk ? rk : rv, (__attribute__((address_space(3))) void*)dst, 16,
-                                             (off & ~oob) | (0xFFFFFFF0u & oob), 0, 0, 0);
+    lds_dma<16, true>(isk ? rk : rv, dst,
+                                               (off & ~oob) | (0xFFFFFFF0u & oob));
   };
   auto issue_batch = [&](int j) __attribute__((always_inline)) {
 #pragma unroll

@@ -99,6 +99,32 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
+// LDS-DMA (buffer_load ... lds), as the builtin or (ASM) as INLINE ASM.  The compiler's waitcnt pass cannot tell the
+// DMA's destination from the source of a later ds_read_b64_tr_b16, so for the builtin it puts s_waitcnt vmcnt(0) in front
+// of the first transposed read after every DMA: the tile requested at the top of an iteration has to LAND before the
+// second half of the same iteration starts, whatever the ring depth.  With two workgroups per CU that wait is hidden
+// (zk_attn_fwd / bwd: no difference between the two forms, profiles/r03_attn_dma_asm_ab.txt, so they keep the builtin);
+// at one wave per SIMD it is not (zk_attn_fwd_w64: +7 % at S = 6144, +30 % at head_dim 64 with the asm form).  A kernel
+// that uses the asm form orders DMA against reads by hand (counted s_waitcnt vmcnt + barrier) and must have waited for
+// every register it loaded in its prologue BEFORE its main loop (a compiler-placed vmcnt(0) at a first use inside the
+// loop would drain the DMA the compiler does not know about).  m0 holds the wave-uniform LDS destination; nothing else
+// in these kernels uses m0 (gfx9 DS instructions do not).
+template <int BYTES, bool ASM = false>
+__device__ __forceinline__ void lds_dma(__amdgpu_buffer_rsrc_t r, const void* lds_dst, unsigned voff) {
+  static_assert(BYTES == 16 || BYTES == 4, "dwordx4 or dword");
+  if constexpr (!ASM) {
+    auto* d = (__attribute__((address_space(3))) void*)const_cast<void*>(lds_dst);
+    if constexpr (BYTES == 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, d, 16, voff, 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(r, d, 4, voff, 0, 0, 0);
+  } else {
+    const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) void*)const_cast<void*>(lds_dst));
+    if constexpr (BYTES == 16)
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m), "v"(voff), "s"(r) : "memory");
+    else
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(m), "v"(voff), "s"(r) : "memory");
+  }
+}
+
 // LDS transposed read: per 16-lane group a 4(row) x 16(col) block of 16-bit elements; the lane
 // 4q+p supplies the address of row q, cols 4p..4p+3; lane i receives column i, rows 0..3.
 __device__ __forceinline__ short4_t lds_read_tr16(const void* lds_addr) {
