@@ -91,7 +91,7 @@ int zk_gemv_fused_bf16(const void* x, const void* W, void* y, int64_t M, int64_t
  *   tile        -1 cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256, 3 = 128x96, 4 = 384x192 (NT ring only),
  *               5 = 192x256 (persistent NT ring; K a multiple of 64)
  *   splits      0 heuristic, 1 never split K, 2..16 force that many splits (plain products with a workspace)
- *   stage_mode  -1 default (1), 0 LDS-DMA for every operand, 1 registers for transposed operands
+ *   stage_mode  -1 default (0), 0 LDS-DMA for every operand, 1 registers for transposed operands
  *   ring        -1 default (1), 0 / 1: 3-stage ring kernel for NT products on the 256x128 tile off / on
  *   lean        -1 default (1), 0 / 1: lean DMA addressing off / on
  *   pring       -1 default (1), 0 / 1: persistent slot ring off / on (on: one workgroup per CU walks its tiles)

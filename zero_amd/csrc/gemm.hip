@@ -94,8 +94,9 @@ __device__ __forceinline__ void tile_dma(__amdgpu_buffer_rsrc_t rs, unsigned cha
     }
     // wave-uniform LDS base of this wave-instruction; the hardware adds lane * 16
     unsigned char* dst = lds + ((tid & ~63) + NT * i) * 16;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16,
-                                             ok ? off : 0xFFFFFFF0u, 0, 0, 0);
+    // (transposed images are read with ds_read_b64_tr_b16: the asm form keeps the compiler from draining the DMA in
+    //  front of the first such read, see lds_dma)
+    lds_dma<16, T>(rs, dst, ok ? off : 0xFFFFFFF0u);
   }
 }
 
@@ -1105,7 +1106,8 @@ namespace {
 struct Plan {
   int tile = -1;         // -1 = cost model, 0 = 128x128, 1 = 256x128, 2 = 256x256, 3 = 128x96, 4 = 384x192
   int splits = 0;        // 0 = heuristic, 1 = never split K, n > 1 = force n splits
-  int stage_mode = 1;    // 0 = LDS-DMA for every operand, 1 = registers for transposed operands
+  int stage_mode = 0;    // 0 = LDS-DMA for every operand (default since round 3: with the DMA as inline asm the compiler no
+                         // longer drains it before the transposed reads, tools/bench_stage.py), 1 = registers for transposed operands
   int ring = 1;          // 1 = 3-stage ring kernel for NT products on the 256x128 tile
   int ring_mode = 0;     // ablations (ZK_ABLATION builds only): 1 = ring without MFMAs, 2 = without DMA, 3 = no epilogue
   int lean = 1;          // 0 = never use the lean DMA path

@@ -537,6 +537,6 @@ def set_gemm_tile(cfg: int = -1):
     else:
         raise ValueError(f"set_gemm_tile: unknown code {cfg}")
     d = GemmPlan.default()
-    same = all(getattr(pl, n) == getattr(d, n) or (n in ("stage_mode", "ring", "lean", "pring") and getattr(pl, n) == 1)
-               for n, _ in GemmPlan._fields_)
+    builtin = {"stage_mode": 0, "ring": 1, "lean": 1, "pring": 1}          # what -1 means inside the library
+    same = all(getattr(pl, n) == getattr(d, n) or builtin.get(n) == getattr(pl, n) for n, _ in GemmPlan._fields_)
     _PLAN = None if same else pl
