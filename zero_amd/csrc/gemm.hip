@@ -857,6 +857,16 @@ __device__ __forceinline__ void store_tile_p(const GemmArgs& g, f32x4 (&acc)[TM]
   });
 }
 
+#ifdef ZK_RING_STAMPS
+// diagnostic build only (tools/ring_stamps.py): where a persistent workgroup's time goes.  100 MHz wall-clock stamps of
+// lane 0 of every wave at tile start / K loop end / epilogue code end, for the first 8 tiles of the first 256 workgroups
+static __device__ unsigned long long g_rstamps[256 * 8 * 8 * 4];
+#define ZK_RSTAMP(ord, k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && (ord) < 8) \
+    g_rstamps[((blockIdx.x * 8 + (ord)) * 8 + (threadIdx.x >> 6)) * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ZK_RSTAMP(ord, k) do { } while (0)
+#endif
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int RS, int NSLOT, bool LEAN, int EPI>
 __global__ __launch_bounds__(512) void gemm_pring_kernel(GemmArgs g) {
   constexpr int NT = 512;
@@ -1051,6 +1061,7 @@ __global__ __launch_bounds__(512) void gemm_pring_kernel(GemmArgs g) {
     // In a continued tile K-tile 1 was waited for before the previous epilogue's stores: its first
     // step must not wait on vmcnt (the stores are still draining behind the MFMAs).
     bool skip_vm = ord > 0;
+    ZK_RSTAMP(ord, 0);
     for (int t = 0; t < nk; ++t) {
       int npos = c_pos + SPT;
       npos = npos >= NSLOT ? npos - NSLOT : npos;
@@ -1065,8 +1076,10 @@ __global__ __launch_bounds__(512) void gemm_pring_kernel(GemmArgs g) {
       burst(fb1, fb0, slot_of(npos, a_part), slot_of(npos, b_part), 0, std::true_type{});
       c_pos = npos;
     }
+    ZK_RSTAMP(ord, 1);
     store_tile_p<TM, TN, WAITN, EPI>(g, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), lane,
                                      smem + NSLOT * SLOT + wv * PATCH);
+    ZK_RSTAMP(ord, 2);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 }
@@ -1099,6 +1112,17 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* slab, b
 }
 
 }  // namespace
+
+#ifdef ZK_RING_STAMPS
+extern "C" int zk_debug_read_ring_stamps(void* host_dst) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_rstamps), sizeof(g_rstamps)) == hipSuccess ? 0 : -5;
+}
+extern "C" int zk_debug_clear_ring_stamps() {
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_rstamps)) != hipSuccess) return -5;
+  return hipMemset(p, 0, sizeof(g_rstamps)) == hipSuccess ? 0 : -5;
+}
+#endif
 
 #ifndef ZK_KERNEL_PROBE   // (probe builds instantiate one kernel for disassembly: tools/probe_kernel.sh)
 namespace {
