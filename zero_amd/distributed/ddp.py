@@ -111,7 +111,7 @@ class FlatGradReducer:
                 p._zk_dirty = False
                 p._zk_sink = self.sink
                 self.offset[id(p)] = o
-        if self.world > 1:
+        if self.world > 1 or self._force:            # (--force-dist: the one-rank rehearsal issues these collectives too)
             # DDP's _sync_module_states (ref:train.py:367): every replica starts from rank 0's parameters AND
             # buffers — the trainable ones in one flat broadcast, the frozen ones (the surrogate decoder, encoder
             # layers 0-15: replicas seeded differently or loaded from different partial checkpoints would train on
