@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ZK_ABI_VERSION 5
+#define ZK_ABI_VERSION 6
 int zk_abi_version(void);
 
 /* ---- GEMM -------------------------------------------------------------------------
@@ -113,9 +113,19 @@ int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t M, int64_t 
  * profiler reports.  kind * 1000 + tile * 100 + lean * 10 + epilogue class; kind 0 = two-stage
  * gemm_kernel, 1 = gemm_ring_kernel, 2 = gemm_ringx_kernel, 3 = gemm_pring_kernel (persistent),
  * 4 = split-K (4000 + splits); tile 0..5 = 128x128, 256x128, 256x256, 128x96, 384x192, 192x256; epilogue
- * class of the persistent kernel: 0 plain / bias / residual / accumulate, 1 quick-GELU pair, 2 SwiGLU pair,
- * 4 erf-GELU pair. */
+ * class of the persistent kernel: 0 plain / bias, 6 the same + residual, 1 quick-GELU pair, 2 SwiGLU forward,
+ * 5 SwiGLU backward, 4 erf-GELU pair. */
 int zk_gemm_last_plan(void);
+
+/* The kernel choice of zk_gemm_bf16_plan for a call of this shape WITHOUT launching anything (no counterpart in the
+ * reference; host logic only, callable without a GPU: tile quantisation model, split-K model, row split, ring
+ * operand limits, argument validation).  has_* say which optional operands the call would pass (alignment is taken
+ * as given).  Returns the zk_gemm_last_plan code the call would leave (for a row-split product: the code of its
+ * whole-round part), or the negative error the call would return. */
+int zk_gemm_plan_query(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int transA,
+                       int transB, int epilogue, int has_bias, int has_residual, int64_t ldr, int has_aux_out,
+                       int has_aux_in, int64_t ldaux, int accumulate, int64_t workspace_bytes,
+                       const zk_gemm_plan_t* plan);
 
 /* ---- fused attention ----------------------------------------------------------------
  * softmax(Q K^T * scale [+ causal mask]) V, flash-style (no S x S matrix in HBM).

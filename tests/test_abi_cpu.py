@@ -19,7 +19,7 @@ def test_header_symbols_exported():
     lib = ctypes.CDLL(os.path.join(ROOT, "zero_amd", "libzero_hip.so"))
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/zero_hip.h but not exported"
-    assert lib.zk_abi_version() == 5
+    assert lib.zk_abi_version() == 6
 
 
 def test_binding_covers_header():

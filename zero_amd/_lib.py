@@ -29,6 +29,7 @@ SIGNATURES = {
     "zk_gemv_fused_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _P, _L, _I, _P, _F, _P],
     "zk_gemm_bf16_plan": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _P, _P, _L, _P, _P, _L, _F, _P, _I, _P, _L, _P, _P],
     "zk_gemm_last_plan": [],
+    "zk_gemm_plan_query": [_L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _I, _L, _I, _I, _L, _I, _L, _P],
     "zk_attn_fwd": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "zk_attn_fwd_w64": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "zk_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P],
@@ -68,7 +69,7 @@ for _name, _args in SIGNATURES.items():
     _fn.argtypes = _args
     _fn.restype = c_int
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 if lib.zk_abi_version() != ABI_VERSION:
     raise ImportError("libzero_hip.so ABI version mismatch; rebuild with `make -C zero_amd/csrc`")
 

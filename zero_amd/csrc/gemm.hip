@@ -1140,6 +1140,11 @@ struct Plan {
   int phase_delay = -1;  // persistent kernel start stagger, 10 ns ticks per phase step (-1 = built-in policy)
 };
 int g_num_cu[16] = {0};
+// zk_gemm_plan_query: the whole decision path of zk_gemm_bf16_plan runs, nothing is launched (host logic, testable
+// without a GPU)
+thread_local bool g_dry_run = false;
+#define ZK_GO(...) do { if (!g_dry_run) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+#define ZK_CHECK_LAUNCH_G() do { if (!g_dry_run) { ZK_CHECK_LAUNCH(); } } while (0)
 thread_local bool g_in_row_split = false;   // the two halves of a row-split product are not split again
 thread_local int g_last_plan = -1;   // kernel variant of this thread's last zk_gemm_bf16 call (zk_gemm_last_plan)
 
@@ -1161,7 +1166,7 @@ void launch_cfg(const GemmArgs& g0, int transA, int transB, hipStream_t stream, 
   g.tiles_n = (g.N + BN - 1) / BN;
   dim3 grid(g.tiles_m * g.tiles_n * g.splits), block(64 * WM_ * WN_);
   const bool reg = P.stage_mode == 1;
-#define ZK_LAUNCH(TA_, TB_, STG_) hipLaunchKernelGGL((gemm_kernel<TA_, TB_, BM, BN, WM_, WN_, STG_>), grid, block, 0, stream, g)
+#define ZK_LAUNCH(TA_, TB_, STG_) ZK_GO((gemm_kernel<TA_, TB_, BM, BN, WM_, WN_, STG_>), grid, block, 0, stream, g)
   if (!transA && !transB) ZK_LAUNCH(false, false, 0);
   else if (transA && !transB) { if (reg) ZK_LAUNCH(true, false, 1); else ZK_LAUNCH(true, false, 0); }
   else if constexpr ((BN & (BN - 1)) == 0) {   // the transposed-B image needs a power-of-two row (swizzle)
@@ -1298,6 +1303,22 @@ int64_t row_split(int64_t M, int64_t N, int64_t K, int transB, bool need_tn4, co
 
 extern "C" int zk_gemm_last_plan(void) { return g_last_plan; }
 
+extern "C" int zk_gemm_plan_query(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int transA,
+                                  int transB, int epilogue, int has_bias, int has_residual, int64_t ldr, int has_aux_out,
+                                  int has_aux_in, int64_t ldaux, int accumulate, int64_t workspace_bytes,
+                                  const zk_gemm_plan_t* plan) {
+  // 16-byte aligned stand-ins that are never dereferenced: with g_dry_run set nothing is launched
+  void* const p = reinterpret_cast<void*>(static_cast<uintptr_t>(0x1000));
+  g_dry_run = true;
+  g_last_plan = -1;
+  const int rc = zk_gemm_bf16_plan(p, p, p, M, N, K, lda, ldb, ldc, transA, transB, epilogue, has_bias ? p : nullptr,
+                                   has_residual ? p : nullptr, ldr, has_aux_out ? p : nullptr, has_aux_in ? p : nullptr,
+                                   ldaux, 1.0f, nullptr, accumulate, workspace_bytes > 0 ? p : nullptr, workspace_bytes,
+                                   plan, nullptr);
+  g_dry_run = false;
+  return rc == ZK_OK ? g_last_plan : rc;
+}
+
 extern "C" int zk_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                             int64_t ldb, int64_t ldc, int transA, int transB, int epilogue, const void* bias,
                             const void* residual, int64_t ldr, void* aux_out, const void* aux_in, int64_t ldaux,
@@ -1408,9 +1429,9 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
     launch_cfg<128, 128, 2, 2>(g, transA, transB, stream, P);
     int64_t nb = (M * (N / 4) + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)nb), dim3(256), 0, stream, g.slab, g.C, g.M, g.N, g.ldc,
+    ZK_GO(splitk_finish_kernel, dim3((unsigned)nb), dim3(256), 0, stream, g.slab, g.C, g.M, g.N, g.ldc,
                        g.splits, alpha, alpha_dev, accumulate);
-    ZK_CHECK_LAUNCH();
+    ZK_CHECK_LAUNCH_G();
     return ZK_OK;
   }
   int tile = choose_tile(M, N, K, transA, transB, epilogue == ZK_EPI_SWIGLU, P);
@@ -1458,11 +1479,11 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
                            : (pclass == 0 || pclass == 6 || pclass == 3) ? 300 : heavy_us * 100;
 #define ZK_PRING(EPI_) \
   do { \
-    if (tile == 5) hipLaunchKernelGGL((gemm_pring_kernel<192, 256, 2, 4, 64, 14, true, EPI_>), pg, dim3(512), 0, stream, gr); \
-    else if (tile == 4 && lean_p) hipLaunchKernelGGL((gemm_pring_kernel<384, 192, 4, 2, 192, 6, true, EPI_>), pg, dim3(512), 0, stream, gr); \
-    else if (tile == 4) hipLaunchKernelGGL((gemm_pring_kernel<384, 192, 4, 2, 192, 6, false, EPI_>), pg, dim3(512), 0, stream, gr); \
-    else if (lean_p) hipLaunchKernelGGL((gemm_pring_kernel<256, 256, 2, 4, 128, 9, true, EPI_>), pg, dim3(512), 0, stream, gr); \
-    else hipLaunchKernelGGL((gemm_pring_kernel<256, 256, 2, 4, 128, 9, false, EPI_>), pg, dim3(512), 0, stream, gr); \
+    if (tile == 5) ZK_GO((gemm_pring_kernel<192, 256, 2, 4, 64, 14, true, EPI_>), pg, dim3(512), 0, stream, gr); \
+    else if (tile == 4 && lean_p) ZK_GO((gemm_pring_kernel<384, 192, 4, 2, 192, 6, true, EPI_>), pg, dim3(512), 0, stream, gr); \
+    else if (tile == 4) ZK_GO((gemm_pring_kernel<384, 192, 4, 2, 192, 6, false, EPI_>), pg, dim3(512), 0, stream, gr); \
+    else if (lean_p) ZK_GO((gemm_pring_kernel<256, 256, 2, 4, 128, 9, true, EPI_>), pg, dim3(512), 0, stream, gr); \
+    else ZK_GO((gemm_pring_kernel<256, 256, 2, 4, 128, 9, false, EPI_>), pg, dim3(512), 0, stream, gr); \
   } while (0)
           if (pclass == 0) ZK_PRING(0);
           else if (pclass == 1) ZK_PRING(1);
@@ -1478,10 +1499,10 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
         g_last_plan = 2000 + tile * 100 + (lean ? 10 : 0);
 #define ZK_RINGX(MODE_) \
   do { \
-    if (tile == 4 && lean) hipLaunchKernelGGL((gemm_ringx_kernel<384, 192, 2, 4, 192, 6, MODE_, true>), rg, dim3(512), 0, stream, gr); \
-    else if (tile == 4) hipLaunchKernelGGL((gemm_ringx_kernel<384, 192, 2, 4, 192, 6, MODE_, false>), rg, dim3(512), 0, stream, gr); \
-    else if (lean) hipLaunchKernelGGL((gemm_ringx_kernel<256, 256, 2, 4, 256, 5, MODE_, true>), rg, dim3(512), 0, stream, gr); \
-    else hipLaunchKernelGGL((gemm_ringx_kernel<256, 256, 2, 4, 256, 5, MODE_, false>), rg, dim3(512), 0, stream, gr); \
+    if (tile == 4 && lean) ZK_GO((gemm_ringx_kernel<384, 192, 2, 4, 192, 6, MODE_, true>), rg, dim3(512), 0, stream, gr); \
+    else if (tile == 4) ZK_GO((gemm_ringx_kernel<384, 192, 2, 4, 192, 6, MODE_, false>), rg, dim3(512), 0, stream, gr); \
+    else if (lean) ZK_GO((gemm_ringx_kernel<256, 256, 2, 4, 256, 5, MODE_, true>), rg, dim3(512), 0, stream, gr); \
+    else ZK_GO((gemm_ringx_kernel<256, 256, 2, 4, 256, 5, MODE_, false>), rg, dim3(512), 0, stream, gr); \
   } while (0)
         if (P.ring_mode == 1) ZK_RINGX(1);
         else if (P.ring_mode == 2) ZK_RINGX(2);
@@ -1499,16 +1520,16 @@ extern "C" int zk_gemm_bf16_plan(const void* A, const void* B, void* C, int64_t 
         gr.tiles_m = (g.M + 255) / 256; gr.tiles_n = (g.N + 127) / 128;
         const dim3 rg(gr.tiles_m * gr.tiles_n);
         g_last_plan = 1000 + tile * 100;
-        if (P.ring_mode == 1) hipLaunchKernelGGL((gemm_ring_kernel<256, 128, 4, 2, 3, 1>), rg, dim3(512), 0, stream, gr);
-        else if (P.ring_mode == 2) hipLaunchKernelGGL((gemm_ring_kernel<256, 128, 4, 2, 3, 2>), rg, dim3(512), 0, stream, gr);
-        else hipLaunchKernelGGL((gemm_ring_kernel<256, 128, 4, 2, 3>), rg, dim3(512), 0, stream, gr);
+        if (P.ring_mode == 1) ZK_GO((gemm_ring_kernel<256, 128, 4, 2, 3, 1>), rg, dim3(512), 0, stream, gr);
+        else if (P.ring_mode == 2) ZK_GO((gemm_ring_kernel<256, 128, 4, 2, 3, 2>), rg, dim3(512), 0, stream, gr);
+        else ZK_GO((gemm_ring_kernel<256, 128, 4, 2, 3>), rg, dim3(512), 0, stream, gr);
       } else {
         launch_cfg<256, 128, 4, 2>(g, transA, transB, stream, P);
       }
       break;
     default: launch_cfg<128, 128, 2, 2>(g, transA, transB, stream, P); break;
   }
-  ZK_CHECK_LAUNCH();
+  ZK_CHECK_LAUNCH_G();
   return ZK_OK;
 }
 #endif  // ZK_KERNEL_PROBE
