@@ -75,8 +75,13 @@ struct KvRing {
 // wave 0 at entry / first tile landed / loop end / stores issued / stores drained, in a buffer nothing else reads.
 static __device__ unsigned long long g_stamps[8 * 16384];
 #define ZK_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+static __device__ unsigned long long g_stamps_dq[8 * 16384], g_stamps_dkdv[8 * 16384];
+#define ZK_STAMP_A(arr, k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) arr[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ZK_STAMP_V(arr, k, v) do { if (threadIdx.x == 0 && blockIdx.x < 16384) arr[blockIdx.x * 8 + (k)] = (unsigned long long)(v); } while (0)
 #else
 #define ZK_STAMP(k) do { } while (0)
+#define ZK_STAMP_A(arr, k) do { } while (0)
+#define ZK_STAMP_V(arr, k, v) do { } while (0)
 #endif
 
 template <int HD, bool CAUSAL>
@@ -212,6 +217,12 @@ __global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_fwd_kernel(AttnArg
 extern "C" int zk_debug_read_stamps(void* host_dst, int nblocks) {
   return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), (size_t)nblocks * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -5;
 }
+extern "C" int zk_debug_read_stamps_bwd(void* host_dst, int nblocks, int which) {
+  const size_t n = (size_t)nblocks * 8 * sizeof(unsigned long long);
+  const hipError_t e = which == 0 ? hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps_dq), n)
+                                  : hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps_dkdv), n);
+  return e == hipSuccess ? 0 : -5;
+}
 #endif
 
 // =========================================================================================
@@ -219,6 +230,7 @@ extern "C" int zk_debug_read_stamps(void* host_dst, int nblocks) {
 // =========================================================================================
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(AttnArgs a) {
+  ZK_STAMP_A(g_stamps_dq, 0);
   using C = Cfg<HD>;
   using R = KvRing<HD, HD == 128 ? 2 : 3>;
   constexpr int KV = R::KV;
@@ -277,6 +289,8 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(Attn
 #pragma unroll
   for (int ds = 0; ds < C::DS; ++ds) asm volatile("" ::"v"(qf[ds]), "v"(dof[ds]));
   asm volatile("" ::"v"(lse2), "v"(dlt));
+  ZK_STAMP_A(g_stamps_dq, 1);
+  ZK_STAMP_V(g_stamps_dq, 5, qblk); ZK_STAMP_V(g_stamps_dq, 6, nt);
 
   for (int t = 0; t < nt; ++t) {
     R::wait_tiles(min(R::NST - 2, nt - 1 - t));
@@ -315,6 +329,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(Attn
       }
     }
   }
+  ZK_STAMP_A(g_stamps_dq, 2);
   // dQ leaves through LDS as whole rows (a lane owns 8 bytes of 16 places in one row of the accumulator layout: 32 rows x 16 bytes per store instruction otherwise): the ring is idle once every wave has
   // passed its last tile; each wave owns a [32][HD] bf16 patch, chunk c of row q at chunk c ^ (q % chunks-per-row)
   constexpr int RPI = 64 / C::CPR;                 // rows per wave-instruction
@@ -366,6 +381,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(Attn
       }
     });
   }
+  ZK_STAMP_A(g_stamps_dq, 3);
 }
 
 // =========================================================================================
@@ -386,6 +402,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(Attn
 // accumulators, so the exchange only reshapes).
 template <int HD, bool CAUSAL, int GW>
 __global__ __launch_bounds__(256 * GW, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
+  ZK_STAMP_A(g_stamps_dkdv, 0);
   using C = Cfg<HD>;
   constexpr int QT = 64, NST = 3, NT = 256 * GW;
   constexpr int RB = HD * 2;                       // LDS row bytes (unpadded)
@@ -474,6 +491,8 @@ __global__ __launch_bounds__(256 * GW, 2) void attn_bwd_dkdv_kernel(AttnArgs a) 
   // (K fragments waited for here, not at their first use inside the loop: see attn_fwd_kernel)
 #pragma unroll
   for (int ds = 0; ds < C::DS; ++ds) asm volatile("" ::"v"(kf[ds]));
+  ZK_STAMP_A(g_stamps_dkdv, 1);
+  ZK_STAMP_V(g_stamps_dkdv, 5, kblk); ZK_STAMP_V(g_stamps_dkdv, 6, niter);
 
   for (int it = 0; it < niter; ++it) {
     // tile `it` has landed (each wave waits for its own pieces, the barrier covers the others'),
@@ -536,6 +555,7 @@ __global__ __launch_bounds__(256 * GW, 2) void attn_bwd_dkdv_kernel(AttnArgs a) 
     }
   }
 
+  ZK_STAMP_A(g_stamps_dkdv, 2);
   // ---- the two query halves meet: every wave parks one accumulator set in its fp32 patch
   // ([32 keys][HD + pad]); wave (g, w) then sums rows 16g..16g+15 of patches (0, w) and (1, w)
   // and writes whole rows (8 consecutive d per lane).  dK first, then dV through the same patches.
@@ -603,6 +623,7 @@ __global__ __launch_bounds__(256 * GW, 2) void attn_bwd_dkdv_kernel(AttnArgs a) 
       *reinterpret_cast<u32x4*>(outp + ((size_t)b * a.S + key) * ldo_ + kvh * HD + ch * 8) = o4;
     }
   }
+  ZK_STAMP_A(g_stamps_dkdv, 3);
 }
 
 bool bad_attn(int64_t B, int64_t S, int64_t Hq, int64_t Hkv, int64_t hd, int64_t l0, int64_t l1, int64_t l2, int64_t l3) {
