@@ -96,6 +96,10 @@ def flops_per_image(enc_layers, ft_after, d, nh, nkv, f, Ld, V, S, T=577, D=1024
     if stage == "pretrain":        # no encoder backward; weight gradients of the translator layer(s)
         enc_bwd = 0
     total = enc_fwd + enc_bwd + 3 * adapter + Ld * (2 * dec_gemm + 3 * dec_attn) + 2 * lm
+    if not full_lm_head:
+        # executed: the last (frozen) layer forms its row-wise half (o-projection, MLP) for the labelled rows only,
+        # forward and backward (functional.DecoderLayerFn, tail rows): nothing reads the other rows of its output
+        total -= 2 * 2 * (S - rows) * (nh * hd * d + 3 * d * f)
     if stage == "pretrain":
         total += n_translators * dec_gemm
     return total

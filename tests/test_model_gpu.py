@@ -441,3 +441,77 @@ def test_trainable_dgrad_transposed_copy_is_refreshed():
     w.data.mul_(2.0)                                         # invisible to autograd, like the fused AdamW kernel
     ZF.bump_weights_epoch()                                  # ... which is why Trainer.optimizer_step bumps the epoch
     assert maxrel(ZF.dgrad_trainable(dy, w), 4 * ref) <= 1e-2
+
+
+@pytest.mark.parametrize("name", ["mid", "tiny"])
+def test_row_restricted_last_layer_equals_the_full_computation(name):
+    """The last (frozen) decoder layer forms its row-wise half only for the labelled rows (functional.DecoderLayerFn,
+    tail rows): loss and every gradient must be those of the full computation — same kernels row by row, only the
+    GEMMs' tile / split-K choice differs with the row count (bf16 rounding of a different summation order)."""
+    from zero_amd.models import llama
+    spec = GOLDEN_CONFIGS[name]
+    enc, dec = spec["enc"], spec["dec"]
+    params = zo.make_params(enc, dec, spec["seed"], surrogate=True)
+    imgs, ids, tgts, img_id, pad_id = zo.synth_batch(enc, dec, **spec["batch"])
+    out = {}
+    old = llama.TAIL_ROWS
+    try:
+        for on in (False, True):
+            llama.TAIL_ROWS = on
+            used = llama.TAIL_ROWS_USED
+            cfg, model, loss, aux, grads = run_hip(spec, params, imgs, ids, tgts, img_id, pad_id)
+            assert (llama.TAIL_ROWS_USED > used) == on, "the batch must qualify: labelled rows <= half of the positions"
+            out[on] = (loss.item(), aux["loss_sum"].item(), aux["inputs_embeds"].grad.clone(), {n: g.clone() for n, g in grads.items()})
+    finally:
+        llama.TAIL_ROWS = old
+    full, tail = out[False], out[True]
+    assert abs(full[0] - tail[0]) <= 2e-4 * abs(full[0]), (full[0], tail[0])
+    assert abs(full[1] - tail[1]) <= 2e-4 * abs(full[1])
+    # (two equally valid bf16 backward passes through the remaining layers: the single-layer test below is the sharp one)
+    assert normrel(tail[2], full[2]) <= 1e-2
+    scale = max(v.float().norm().item() / v.numel() ** 0.5 for v in full[3].values())
+    worst = max((grad_err(tail[3][n], full[3][n], scale * full[3][n].numel() ** 0.5), n) for n in full[3])
+    print(name, "loss", full[0], tail[0], "d_inputs", normrel(tail[2], full[2]), "worst grad", worst)
+    assert worst[0] <= 1e-2, worst
+
+
+def test_row_restricted_decoder_layer_node():
+    """One DecoderLayerFn with and without the row list, same inputs: the listed output rows agree to the last bit up to
+    the rounding of a different summation order (a few elements one bf16 ulp apart), and so does the input gradient when
+    only the listed rows carry an output gradient."""
+    from zero_amd import functional as ZF
+    torch.manual_seed(7)
+    B, S, d, nh, nkv, hd, F = 2, 256, 512, 4, 2, 128, 1024
+    M = B * S
+    g = lambda *shape, s=0.05: (torch.randn(*shape, device=DEV) * s).to(torch.bfloat16)
+    x = g(B, S, d, s=1.0)
+    l1w, l2w = (1 + g(d, s=0.1)), (1 + g(d, s=0.1))
+    qw, kw, vw, ow = g(nh * hd, d), g(nkv * hd, d), g(nkv * hd, d), g(d, nh * hd)
+    gw, uw, dw = g(F, d), g(F, d), g(d, F)
+    pos = torch.arange(S, dtype=torch.float32)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    fr = pos[:, None] * inv[None, :]
+    cos_t, sin_t = fr.cos().to(DEV).contiguous(), fr.sin().to(DEV).contiguous()
+    rows = torch.sort(torch.randperm(M)[:96]).values.to(torch.int32).to(DEV)
+    inv_rows = torch.full((M,), -1, dtype=torch.int32, device=DEV)
+    inv_rows[rows.long()] = torch.arange(rows.numel(), dtype=torch.int32, device=DEV)
+    dy_rows = g(1, rows.numel(), d, s=1.0)
+    outs = {}
+    for tail in (False, True):
+        xi = x.clone().requires_grad_(True)
+        y = ZF.DecoderLayerFn.apply(xi, l1w, qw, kw, vw, ow, l2w, gw, uw, dw, cos_t, sin_t, (nh, nkv, hd, 1e-5),
+                                    rows if tail else None, inv_rows if tail else None)
+        if tail:
+            assert y.shape == (1, rows.numel(), d)
+            y.backward(dy_rows)
+            yr = y[0]
+        else:
+            dy = torch.zeros(M, d, dtype=torch.bfloat16, device=DEV)
+            dy[rows.long()] = dy_rows[0]
+            y.backward(dy.view(B, S, d))
+            yr = y.reshape(M, d)[rows.long()]
+        outs[tail] = (yr.detach().float(), xi.grad.detach().float())
+    yf, yt = outs[False][0], outs[True][0]
+    diff = (yf - yt).abs()
+    assert float((diff > 0).float().mean()) <= 0.02 and float((diff / yf.abs().clamp_min(1e-2)).max()) <= 1.0 / 64
+    assert normrel(outs[True][1], outs[False][1]) <= 2e-3

@@ -495,10 +495,17 @@ class EncoderLayerFn(torch.autograd.Function):
 # for the seven weight gradients, RMSNorm weight gradients by zk_rmsnorm_dweight.
 # ------------------------------------------------------------------------------------------
 class DecoderLayerFn(torch.autograd.Function):
-    """inputs: x [B,S,d]; ln1.w; q.w k.w v.w o.w; ln2.w; gate.w up.w down.w; cos, sin; cfg tuple."""
+    """inputs: x [B,S,d]; ln1.w; q.w k.w v.w o.w; ln2.w; gate.w up.w down.w; cos, sin; cfg tuple.
+
+    ``rows`` / ``inv_rows`` (int32, both or neither; LAST layer of a frozen decoder only): the flat positions whose
+    output anything reads (the rows the loss is formed on) and the inverse map position -> index or -1.  Everything
+    behind the attention of a decoder layer is row-wise (o-projection, residual adds, RMSNorm, the MLP), and no later
+    layer attends to this layer's output, so the output rows that are not listed feed nothing: the node then returns
+    the listed rows only, as [1, R, d], and its backward takes their gradient.  Keys, values and the attention itself
+    still cover every position; loss and gradients are those of the full computation."""
 
     @staticmethod
-    def forward(ctx, x, l1w, qw, kw, vw, ow, l2w, gw, uw, dw, cos_t, sin_t, dims):
+    def forward(ctx, x, l1w, qw, kw, vw, ow, l2w, gw, uw, dw, cos_t, sin_t, dims, rows=None, inv_rows=None):
         nh, nkv, hd, eps = dims
         B, S, d = x.shape
         M = B * S
@@ -520,7 +527,13 @@ class DecoderLayerFn(torch.autograd.Function):
         ops.rope_(qkv, cos_t, sin_t, S, nh + nkv, hd)
         q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
         ao, lse = ops.attn_fwd(q, k, v, B, S, nh, nkv, hd, hd ** -0.5, S > 1, need_lse=need)
-        xa = ops.gemm(ao, ow, residual=x2)
+        tail = rows is not None
+        if tail and trainable:
+            raise ValueError("DecoderLayerFn: the row-restricted tail is for frozen layers")
+        if tail:
+            xa = ops.gemm(ops.gather_rows(ao, None, rows, ao.shape[1]), ow, residual=ops.gather_rows(x2, None, rows, d))
+        else:
+            xa = ops.gemm(ao, ow, residual=x2)
         h2, rstd2 = ops.rmsnorm_fwd(xa, l2w, eps, save_stats=need)
         F = gw.shape[0]
         fused = (FUSE_SWIGLU and USE_TRANSPOSED_FROZEN and F % 32 == 0 and not trainable
@@ -534,7 +547,7 @@ class DecoderLayerFn(torch.autograd.Function):
             gu = ops.gemm(h2, wgu)
             hm = ops.swiglu_fwd(gu, F)
         else:
-            gu = torch.empty((M, 2 * F), dtype=BF16, device=x.device)
+            gu = torch.empty((h2.shape[0], 2 * F), dtype=BF16, device=x.device)
             ops.gemm(h2, gw, out=gu[:, :F])
             ops.gemm(h2, uw, out=gu[:, F:])
             hm = ops.swiglu_fwd(gu, F)
@@ -542,20 +555,22 @@ class DecoderLayerFn(torch.autograd.Function):
         if need:
             extra = (h1, h2, hm) if trainable else (None, None, None)
             ctx.save_for_backward(x2, rstd1, qkv, ao, lse, xa, rstd2, gu, l1w, qw, kw, vw, ow, l2w, gw, uw, dw,
-                                  cos_t, sin_t, *extra)
+                                  cos_t, sin_t, *extra, *((inv_rows,) if tail else ()))
             ctx.dims = (B, S, d, nh, nkv, hd, F)
             ctx.fused_swiglu = fused
-        return y.view(B, S, d)
+            ctx.tail = tail
+        return y.view(1, -1, d) if tail else y.view(B, S, d)
 
     @staticmethod
     def backward(ctx, dy):
         (x2, rstd1, qkv, ao, lse, xa, rstd2, gu, l1w, qw, kw, vw, ow, l2w, gw, uw, dw, cos_t, sin_t,
-         h1, h2, hm) = ctx.saved_tensors
+         h1, h2, hm) = ctx.saved_tensors[:22]
+        inv_rows = ctx.saved_tensors[22] if ctx.tail else None
         GradSink.bind(l1w, qw, kw, vw, ow, l2w, gw, uw, dw)
         B, S, d, nh, nkv, hd, F = ctx.dims
         M = B * S
         nig = ctx.needs_input_grad
-        dy2 = dy.reshape(M, d)
+        dy2 = dy.reshape(-1, d)          # (row-restricted tail: R rows, otherwise M)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         f32 = lambda n: GradSink.parts(ops.norm_parts(M), n, dy.device)      # RMSNorm weight partial sums
@@ -580,6 +595,10 @@ class DecoderLayerFn(torch.autograd.Function):
             g_l2w = _vec_grad(ops.rmsnorm_dweight_(d_h2, xa, rstd2, f32(d)), l2w, True)
         dxa = ops.rmsnorm_bwd(d_h2, xa, l2w, rstd2, dres=dy2)
         d_ao = dgrad(dxa, ow)
+        if inv_rows is not None:
+            # back to every position: the rows nothing read have no gradient (zero rows through the inverse map)
+            d_ao = ops.gather_rows(d_ao, None, inv_rows, d_ao.shape[1])
+            dxa = ops.gather_rows(dxa, None, inv_rows, d)
         g_ow = _wgrad(dxa, ao, ow, nig[5])
         d_qkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
@@ -603,7 +622,7 @@ class DecoderLayerFn(torch.autograd.Function):
             if nig[0]:
                 dx = ops.rmsnorm_bwd(d_h1, x2, l1w, rstd1, dres=dxa).view(B, S, d)
         GradSink.flush()
-        return (dx, g_l1w, g_qw, g_kw, g_vw, g_ow, g_l2w, g_gw, g_uw, g_dw, None, None, None)
+        return (dx, g_l1w, g_qw, g_kw, g_vw, g_ow, g_l2w, g_gw, g_uw, g_dw, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------
@@ -706,19 +725,21 @@ class LMHeadLossFn(torch.autograd.Function):
             x2 = x2.contiguous()
         need = ctx.needs_input_grad[0]
         acc = torch.zeros(2, dtype=torch.float32, device=hidden.device)
-        n = rows.numel()
+        n = rows.numel() if rows is not None else x2.shape[0]
         if n == 0:
             ctx.empty = True
             ctx.shape = hidden.shape
             return acc[0]
-        xs = ops.gather_rows(x2, None, rows, d)
+        # rows None: ``hidden`` already holds exactly the listed rows (row-restricted last decoder layer)
+        xs = ops.gather_rows(x2, None, rows, d) if rows is not None else x2
         hn, rstd = ops.rmsnorm_fwd(xs, norm_w, eps, save_stats=need)
         logits = ops.gemm(hn, lm_w)
         ops.cross_entropy(logits, labels, acc, logits if need else None)
         ctx.empty = False
         ctx.shape = hidden.shape
+        ctx.compact = rows is None
         if need:
-            ctx.save_for_backward(xs, rstd, logits, norm_w, lm_w, inv_rows)
+            ctx.save_for_backward(xs, rstd, logits, norm_w, lm_w, *(() if ctx.compact else (inv_rows,)))
         return acc[0]
 
     @staticmethod
@@ -726,12 +747,14 @@ class LMHeadLossFn(torch.autograd.Function):
         B, S, d = ctx.shape
         if ctx.empty:
             return (torch.zeros(ctx.shape, dtype=BF16, device=g.device),) + (None,) * 7
-        xs, rstd, dlogits, norm_w, lm_w, inv = ctx.saved_tensors
+        xs, rstd, dlogits, norm_w, lm_w = ctx.saved_tensors[:5]
         g32 = g.reshape(1).to(torch.float32).contiguous()
         d_hn = dgrad(dlogits, lm_w, owner=ctx.lm_owner, alpha_dev=g32)
         d_xs = ops.rmsnorm_bwd(d_hn, xs, norm_w, rstd)
+        if ctx.compact:
+            return (d_xs.view(B, S, d),) + (None,) * 7
         # scatter the listed rows back through the inverse map (-1 = no gradient: zero row)
-        dx = ops.gather_rows(d_xs, None, inv, d)
+        dx = ops.gather_rows(d_xs, None, ctx.saved_tensors[5], d)
         return (dx.view(B, S, d),) + (None,) * 7
 
 

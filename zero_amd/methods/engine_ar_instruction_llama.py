@@ -221,9 +221,12 @@ def forward_from_ids(self, cfg, imgs: List[torch.Tensor], input_ids, targets, im
                                       dev["inv_codes"], dev["soi_pos"], dev["eoi_pos"], B, S)
     dec = self.decoder
     if hasattr(dec.model, "run_layers"):
-        hidden = dec.model.run_layers(inputs_embeds)
+        # only the labelled rows of the final hidden state are read: the last (frozen) layer need not form the others
+        hidden = dec.model.run_layers(inputs_embeds, tail_rows=(dev["rows"], dev["inv_rows"]))
+        compact = hidden.shape[:2] != inputs_embeds.shape[:2]
         loss = ZF.LMHeadLossFn.apply(hidden, dec.model.norm.weight.detach(), dec.lm_head.weight.detach(),
-                                     dev["rows"], dev["row_labels"], dev["inv_rows"],
+                                     None if compact else dev["rows"], dev["row_labels"],
+                                     None if compact else dev["inv_rows"],
                                      dec.model.norm.variance_epsilon, (dec.lm_head.weight,))
         logits = None
     else:   # any module with the HF call contract (engine:276-280)

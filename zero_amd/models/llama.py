@@ -15,6 +15,8 @@ import math
 from dataclasses import dataclass, field
 from typing import Dict, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -58,6 +60,10 @@ def llama3_inv_freq(cfg: LlamaConfig) -> torch.Tensor:
     smoothed = (1 - smooth) * inv_l / factor + smooth * inv_l
     medium = ~(wavelen < high_wl) * ~(wavelen > low_wl)
     return torch.where(medium, smoothed, inv_l)
+
+
+TAIL_ROWS = os.environ.get("ZERO_AMD_TAIL_ROWS", "1") != "0"      # A/B switch: 0 = the last layer computes every row
+TAIL_ROWS_USED = 0          # forwards that took the row-restricted tail (tests)
 
 
 class LlamaRotaryEmbedding(nn.Module):
@@ -114,13 +120,14 @@ class LlamaDecoderLayer(nn.Module):
         self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device=device)
         self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device=device)
 
-    def forward(self, hidden_states, position_embeddings=None, **kwargs):
+    def forward(self, hidden_states, position_embeddings=None, tail_rows=None, **kwargs):
         cos_t, sin_t = position_embeddings
         a, m = self.self_attn, self.mlp
+        rows, inv = tail_rows if tail_rows is not None else (None, None)
         return ZF.DecoderLayerFn.apply(
             hidden_states, self.input_layernorm.weight, a.q_proj.weight, a.k_proj.weight, a.v_proj.weight,
             a.o_proj.weight, self.post_attention_layernorm.weight, m.gate_proj.weight, m.up_proj.weight,
-            m.down_proj.weight, cos_t, sin_t, self.cfg_dims)
+            m.down_proj.weight, cos_t, sin_t, self.cfg_dims, rows, inv)
 
 
 class LlamaModel(nn.Module):
@@ -135,13 +142,24 @@ class LlamaModel(nn.Module):
     def get_input_embeddings(self):
         return self.embed_tokens
 
-    def run_layers(self, inputs_embeds):
+    def run_layers(self, inputs_embeds, tail_rows=None):
+        """``tail_rows`` = (rows, inv_rows): the only positions whose final hidden state the caller reads (the rows a
+        loss is formed on).  If the last layer is frozen and fewer than half of the positions are listed, that layer
+        computes its row-wise half (o-projection, MLP) for the listed rows only and the result is [1, R, d] — check
+        ``.shape`` (functional.DecoderLayerFn); otherwise, and without the argument, [B, S, d] as ever."""
         B, S, _ = inputs_embeds.shape
         pe = self.rotary_emb.tables(S, inputs_embeds.device)
         x = inputs_embeds
         # like tf:llama:402 the loop covers whatever the ModuleList holds after the surgery
-        for layer in self.layers[: self.config.num_hidden_layers]:
-            x = layer(x, position_embeddings=pe)
+        layers = self.layers[: self.config.num_hidden_layers]
+        for i, layer in enumerate(layers):
+            tail = None
+            if (tail_rows is not None and TAIL_ROWS and i == len(layers) - 1 and 0 < tail_rows[0].numel() * 2 <= B * S
+                    and not any(p.requires_grad for p in layer.parameters())):
+                tail = tail_rows
+                global TAIL_ROWS_USED
+                TAIL_ROWS_USED += 1
+            x = layer(x, position_embeddings=pe, tail_rows=tail)
         return x
 
     def forward(self, input_ids=None, inputs_embeds=None, **kwargs):
