@@ -533,7 +533,12 @@ def main():
                                     "c2": "ViT-L/14-336 encoder + adapter forward/backward"}[args.workload],
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": S, "image": "336x336",
                        "parallelism": f"dp{world}", "grad_accum": 1, "weights": "seeded random init",
-                       "stage": args.stage},
+                       "stage": args.stage,
+                       # exact dead-row elimination, counted in tflop_per_image_executed
+                       "rows_computed": ("lm_head and the last decoder layer's row-wise half on the labelled rows only "
+                                         "(loss and gradients of the full computation)"
+                                         if args.workload != "c2" and os.environ.get("ZERO_AMD_TAIL_ROWS", "1") != "0"
+                                         else "lm_head on the labelled rows only" if args.workload != "c2" else "all")},
             "loss": round(float(loss), 4),
             "tflop_per_image_algorithmic": round(fl_alg / 1e12, 3),
             "tflop_per_image_executed": round(fl_exec / 1e12, 3),
