@@ -710,6 +710,11 @@ __device__ __forceinline__ void store_tile_p(const GemmArgs& g, f32x4 (&acc)[TM]
   constexpr int AUXD = (TM * TN > 32 && NLD == 2) ? 2 : 4;
   static_assert(WAITN + NLD * AUXD <= 63, "vmcnt field");
   constexpr unsigned OOB = 0x80000000u;                  // past every descriptor (host: operands under 2 GiB)
+  // An opaque copy of the lane id: the patch addresses and row / column indices below are loop-invariant, and hoisted
+  // out of the persistent tile loop they stay live across the K loop — the 384x192 tile (144 accumulators + 72 fragment
+  // registers) then spills, and the spill reloads sit in the first K-step of every tile behind a vmcnt(0).  Recomputing
+  // them per tile costs ~10 vector instructions.
+  asm volatile("" : "+v"(lane));
   const int wr = lane & 15, wg = lane >> 4, rr = lane >> 2, rq = lane & 3;
   unsigned char* wp0 = patch + wr * 128 + ((wg ^ patch_swz(wr)) << 4);
   unsigned char* wp1 = patch + wr * 128 + (((4 + wg) ^ patch_swz(wr)) << 4);
